@@ -1,0 +1,183 @@
+"""ctypes wrapper around oracle/build/libmas_oracle.so -- CPU ORACLE (test infrastructure).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module, and only as the checker / CPU baseline.  The product package
+(multi_agent_solver_amd) never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "libmas_oracle.so")
+
+MODEL_SINGLE_TRACK = 1
+MODEL_LQR_IDENTITY = 2
+MODEL_PENDULUM = 3
+MODEL_SINGLE_TRACK_LANE = 4
+MODEL_BICYCLE6 = 5
+
+STRATEGY = {"sequential": 0, "trustregion": 1, "linesearch": 2, "centralized_dense": 3,
+            "centralized": 4, "single": 5}
+
+
+class StrategyStats(C.Structure):
+    _fields_ = [("total_iterations", C.c_long), ("converged_solves", C.c_long),
+                ("reg_events", C.c_long), ("trials", C.c_long), ("alpha_hist", C.c_int * 12)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("mas_oracle.c", "mas_oracle.h", "ref_unit_cases.c", "Makefile")):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        d = C.POINTER(C.c_double)
+        i = C.POINTER(C.c_int)
+        _lib.mas_oracle_solve_batch.restype = C.c_double
+        _lib.mas_oracle_solve_batch.argtypes = [C.c_int, d, C.c_int, C.c_int, C.c_double, d, d, d, d, i,
+                                                C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                C.POINTER(StrategyStats)]
+        _lib.mas_model_dims.argtypes = [C.c_int, i, i, i]
+        _lib.mas_model_default_params.argtypes = [C.c_int, C.c_int, d]
+        _lib.mas_oracle_max_threads.restype = C.c_int
+        for name in ("mas_ref_case_initialize", "mas_ref_case_update_initial", "mas_ref_case_global",
+                     "mas_ref_case_fd_gradient"):
+            getattr(_lib, name).argtypes = [d]
+            getattr(_lib, name).restype = C.c_int
+        _lib.mas_model_make_ocp.restype = C.c_void_p
+        _lib.mas_model_make_ocp.argtypes = [C.c_int, C.c_int, C.c_double, d, d, d, C.c_size_t]
+        _lib.mas_ocp_free.argtypes = [C.c_void_p]
+        _lib.mas_ilqr_backward_pass.restype = C.c_long
+        _lib.mas_ilqr_backward_pass.argtypes = [C.c_void_p, d, d, d, d, d]
+        _lib.mas_integrate_horizon.argtypes = [C.c_void_p, d, d, C.c_double, d]
+        _lib.mas_ocp_objective.restype = C.c_double
+        _lib.mas_ocp_objective.argtypes = [C.c_void_p, d, d]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def model_dims(model_id: int):
+    nx, nu, npar = C.c_int(), C.c_int(), C.c_int()
+    if lib().mas_model_dims(model_id, C.byref(nx), C.byref(nu), C.byref(npar)):
+        raise ValueError(f"unknown model {model_id}")
+    return nx.value, nu.value, npar.value
+
+
+def default_params(model_id: int, T: int) -> np.ndarray:
+    p = np.zeros(16)
+    lib().mas_model_default_params(model_id, T, _p(p))
+    return p
+
+
+def max_threads() -> int:
+    return lib().mas_oracle_max_threads()
+
+
+def solve_batch(model_id, x0, U0, T, dt, strategy="sequential", max_outer=10, max_iterations=100,
+                tolerance=1e-5, max_ms=math.inf, params=None, threads=0):
+    """Run a strategy over N agents.  x0 [N,nx]; U0 [N,T,nu] (reference column layout: one
+    control column per step) or None for zeros.  Returns dict(X [N,T+1,nx], U [N,T,nu], cost [N],
+    iters [N], total_cost, stats)."""
+    nx, nu, _ = model_dims(model_id)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, nx)
+    N = x0.shape[0]
+    U = np.zeros((N, T, nu)) if U0 is None else np.ascontiguousarray(U0, dtype=np.float64).reshape(N, T, nu).copy()
+    X = np.zeros((N, T + 1, nx))
+    cost = np.zeros(N)
+    iters = np.zeros(N, dtype=np.int32)
+    st = StrategyStats()
+    par = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    if par is not None and par.size < 16:
+        par = np.concatenate([par, np.zeros(16 - par.size)])
+    total = lib().mas_oracle_solve_batch(model_id, _p(par), N, T, float(dt), _p(x0), _p(U), _p(X), _p(cost),
+                                         iters.ctypes.data_as(C.POINTER(C.c_int)), STRATEGY[strategy], max_outer,
+                                         max_iterations, float(tolerance), float(max_ms), threads, C.byref(st))
+    return dict(X=X, U=U, cost=cost, iters=iters, total_cost=total,
+                stats=dict(total_iterations=st.total_iterations, converged_solves=st.converged_solves,
+                           reg_events=st.reg_events, trials=st.trials, alpha_hist=list(st.alpha_hist)))
+
+
+def backward_pass(model_id, x0, U, T, dt, params=None):
+    """Roll out U from x0, then one backward pass (linearisation + Riccati) for ONE agent.
+    Returns X [T+1,nx], cost, k [T,nu], K [T,nu,nx] (K[t,i,j]), derivs dict, reg_events."""
+    nx, nu, _ = model_dims(model_id)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(nx)
+    U = np.ascontiguousarray(U, dtype=np.float64).reshape(T, nu)
+    par = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    o = lib().mas_model_make_ocp(model_id, T, float(dt), _p(x0), _p(U), _p(par), 0)
+    try:
+        X = np.zeros((T + 1, nx))
+        lib().mas_integrate_horizon(o, _p(x0), _p(U), float(dt), _p(X))
+        cost = lib().mas_ocp_objective(o, _p(X), _p(U))
+        k = np.zeros((T, nu))
+        Kc = np.zeros((T, nx, nu))  # column-major nu x nx per step
+        ds = nx * nx + nx * nu + nx + nu + nx * nx + nu * nu + nu * nx
+        D = np.zeros((T, ds))
+        regs = lib().mas_ilqr_backward_pass(o, _p(X), _p(U), _p(k), _p(Kc), _p(D))
+    finally:
+        lib().mas_ocp_free(o)
+    off = 0
+    derivs = {}
+    for name, (r, c) in (("A", (nx, nx)), ("B", (nx, nu)), ("lx", (nx, 1)), ("lu", (nu, 1)),
+                         ("lxx", (nx, nx)), ("luu", (nu, nu)), ("lux", (nu, nx))):
+        blk = D[:, off:off + r * c].reshape(T, c, r).transpose(0, 2, 1)  # col-major -> [t, row, col]
+        derivs[name] = blk[:, :, 0] if c == 1 else blk
+        off += r * c
+    return dict(X=X, cost=cost, k=k, K=Kc.transpose(0, 2, 1), derivs=derivs, reg_events=regs)
+
+
+def ref_case(name: str) -> np.ndarray:
+    out = np.zeros(32)
+    n = getattr(lib(), f"mas_ref_case_{name}")(_p(out))
+    return out[:n].copy()
+
+
+# ----------------------------------------------------------------- workloads --
+def single_track_x0(N: int, track_radius: float = 20.0) -> np.ndarray:
+    """examples/multi_agent_single_track.cpp:41-45,113-117: agent i at theta = 2*pi*i/N."""
+    x0 = np.zeros((N, 4))
+    for i in range(N):
+        theta = 2.0 * math.pi * i / N
+        x0[i] = (track_radius * math.cos(theta), track_radius * math.sin(theta), 1.57 + theta, 4.0)
+    return x0
+
+
+def lqr_x0(N: int, nx: int = 4) -> np.ndarray:
+    x0 = np.zeros((N, nx))
+    x0[:, 0] = 1.0  # examples/multi_agent_lqr.cpp:29-32
+    return x0
+
+
+def pendulum_problem(T: int = 60, dt: float = 0.05):
+    """examples/pendulum_swing_up.cpp:36-44,105-113."""
+    x0 = np.array([[math.pi - 0.05, 0.0]])
+    torque_max = 5.0
+    U0 = np.array([0.2 * torque_max * math.sin(2.0 * math.pi * (k * dt)) for k in range(T)]).reshape(1, T, 1)
+    return x0, U0
+
+
+def bicycle6_x0(N: int, track_radius: float = 20.0) -> np.ndarray:
+    x0 = np.zeros((N, 6))
+    st = single_track_x0(N, track_radius)
+    x0[:, :4] = st
+    return x0
