@@ -1,0 +1,159 @@
+/*
+ * mas_hip.h -- C ABI of the MI355X batched iLQR path (libmas_hip.so).
+ *
+ * Drop-in boundary for `--solver ilqr` of markomiz/multi_agent_solver.  The reference has
+ * no FFI: its "plugin" API is a closed std::variant of solver classes
+ * (include/multi_agent_solver/solvers/solver.hpp:17-45) whose alternatives provide
+ * set_params(SolverParams) and solve(OCP&), called once per agent inside the OpenMP
+ * loops of include/multi_agent_solver/strategies/nash.hpp:59-64,200-212 or once on the
+ * stacked problem (strategies/centralized.hpp:22-23).  The GPU batching boundary is one
+ * level above solve(OCP&): the whole per-agent loop of a strategy becomes one call here.
+ * INTEGRATION.md shows the reference-side binding (a `HipILQR` variant alternative and
+ * batched strategy bodies) that a maintainer would add on top of these entry points.
+ *
+ * Conventions
+ *  - plain C, opaque handle, integer status codes (0 = MAS_HIP_OK), no exceptions;
+ *  - every array at this boundary is FP64 in the REFERENCE layout: per agent a
+ *    column-major Eigen matrix, i.e. states [N][T+1][nx] and controls [N][T][nu] with the
+ *    column of one time step contiguous (types.hpp:14-19); the SoA device layout is internal;
+ *  - `*_host` entry points take host pointers (one PCIe copy each way); `*_device` ones take
+ *    device pointers in the same layout (used with torch tensors' data_ptr());
+ *  - a handle is bound to one HIP device and one stream and is not thread-safe
+ *    (one handle per GPU, as one rank per GPU under torch.distributed).
+ */
+#ifndef MAS_HIP_H
+#define MAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAS_HIP_ABI_VERSION 1
+
+enum mas_hip_status {
+  MAS_HIP_OK = 0,
+  MAS_HIP_ERR_INVALID = 1,     /* bad argument / unknown model / missing parameter */
+  MAS_HIP_ERR_NO_DEVICE = 2,   /* no HIP device: the product never falls back to the CPU */
+  MAS_HIP_ERR_RUNTIME = 3,     /* a HIP call failed; see mas_hip_last_error()            */
+  MAS_HIP_ERR_STATE = 4        /* call order violated (e.g. solve before set_initial)    */
+};
+
+/* Registered workload models (device functors replace the reference's std::function
+ * callbacks, types.hpp:21-50, which cannot run on a GPU).  Values match the oracle's. */
+enum mas_hip_model {
+  MAS_HIP_MODEL_SINGLE_TRACK      = 1, /* examples/multi_agent_single_track.cpp:32-72, models/single_track_model.hpp:23-44; FD derivatives */
+  MAS_HIP_MODEL_LQR_IDENTITY      = 2, /* examples/multi_agent_lqr.cpp:21-76; analytic derivatives */
+  MAS_HIP_MODEL_PENDULUM          = 3, /* examples/pendulum_swing_up.cpp:29-117, models/pendulum_model.hpp:8-20; FD */
+  MAS_HIP_MODEL_SINGLE_TRACK_LANE = 4, /* examples/single_track_ocp.cpp:14-116; analytic except cross term */
+  MAS_HIP_MODEL_BICYCLE6          = 5  /* this repository's own 6-state model (BASELINE config 5) */
+};
+
+/* per-agent exit status of the most recent solve (extension: the reference's solve()
+ * returns nothing, ilqr.hpp:58-273) */
+enum mas_hip_exit {
+  MAS_HIP_EXIT_CONVERGED = 0,  /* improvement < tolerance, ilqr.hpp:269-271 */
+  MAS_HIP_EXIT_MAX_ITER  = 1,  /* iter == max_iterations,  ilqr.hpp:82      */
+  MAS_HIP_EXIT_TIME      = 2,  /* elapsed_ms > max_ms,     ilqr.hpp:84-90   */
+  MAS_HIP_EXIT_NONFINITE = 4   /* flag OR-ed in: a non-finite cost was met   */
+};
+
+typedef struct mas_hip_solver mas_hip_solver;
+
+/* Problem description: what an OCP carries besides its callbacks (ocp.hpp:30-60). */
+typedef struct mas_hip_problem_desc {
+  int32_t model_id;                   /* enum mas_hip_model                                   */
+  int32_t n_agents;                   /* N >= 1                                               */
+  int32_t horizon_steps;              /* T >= 1                                               */
+  int32_t device;                     /* HIP device ordinal                                   */
+  double  dt;
+  const double* params;               /* model constants (16 doubles) or NULL = example's     */
+  const double* input_lower_bounds;   /* nu values or NULL; clamping needs both (ilqr.hpp:213) */
+  const double* input_upper_bounds;   /* NULL,NULL = the model definition's own bounds; pass   */
+  int32_t no_input_bounds;            /* 1 to force "no bounds"                               */
+  int32_t reserved;
+} mas_hip_problem_desc;
+
+/* ---- lifetime ---- */
+int mas_hip_abi_version(void);
+int mas_hip_device_count(void);
+int mas_hip_model_dims(int model_id, int* nx, int* nu);
+int mas_hip_model_default_params(int model_id, int horizon_steps, double* params16);
+int mas_hip_create(const mas_hip_problem_desc* desc, mas_hip_solver** out);
+int mas_hip_create_on_stream(const mas_hip_problem_desc* desc, void* hip_stream, mas_hip_solver** out);
+int mas_hip_destroy(mas_hip_solver*);
+const char* mas_hip_last_error(const mas_hip_solver*);   /* NULL handle: last create() error */
+
+/* ---- solver parameters: iLQR::set_params, ilqr.hpp:39-55 ----
+ * keys "max_iterations", "tolerance", "max_ms" (required by the reference: params.at()),
+ * optional "debug"; the penalty* keys are accepted and ignored (augmented-Lagrangian branch
+ * is out of scope); unknown keys are ignored like the reference. */
+int mas_hip_set_param(mas_hip_solver*, const char* key, double value);
+/* fails with MAS_HIP_ERR_INVALID if a required key was never set (mirrors std::out_of_range) */
+int mas_hip_check_params(const mas_hip_solver*);
+
+/* ---- problem data: OCP::initial_state, OCP::best_controls (warm start, ilqr.hpp:72-75) ---- */
+int mas_hip_set_initial_states_host(mas_hip_solver*, const double* x0 /* [N][nx] */);
+int mas_hip_set_controls_host(mas_hip_solver*, const double* U /* [N][T][nu] or NULL = zeros */);
+int mas_hip_set_initial_states_device(mas_hip_solver*, const void* x0_dev);
+int mas_hip_set_controls_device(mas_hip_solver*, const void* U_dev);
+/* OCP::initialize_problem (ocp.hpp:102-183): roll out the current controls, set best_cost. */
+int mas_hip_initialize_problem(mas_hip_solver*);
+/* snapshot / restore of (x0, controls) on the device, so a benchmark can repeat a run with
+ * its inputs already resident in HBM */
+int mas_hip_save_initial(mas_hip_solver*);
+int mas_hip_restore_initial(mas_hip_solver*);
+
+/* ---- the hot path ---- */
+/* N x iLQR::solve (ilqr.hpp:58-273) == first loop of detail::sequential_solve, nash.hpp:59-64 */
+int mas_hip_solve(mas_hip_solver*);
+/* detail::run_sequential, nash.hpp:74-90 */
+int mas_hip_run_sequential(mas_hip_solver*, int max_outer);
+/* detail::run_trust_region, nash.hpp:182-248 */
+int mas_hip_run_trust_region(mas_hip_solver*, int max_outer);
+/* detail::run_line_search, nash.hpp:92-180 */
+int mas_hip_run_line_search(mas_hip_solver*, int max_outer);
+/* CentralizedStrategy::operator(), centralized.hpp:18-38, under the exact block-diagonal
+ * reading of the stacked problem: shared alpha / acceptance / termination / regularisation */
+int mas_hip_run_centralized(mas_hip_solver*);
+
+/* ---- results: OCP::best_states/best_controls/best_cost; Solution (solution.hpp:9-15) ---- */
+int mas_hip_get_solution_host(mas_hip_solver*, double* X /* [N][T+1][nx] */, double* U /* [N][T][nu] */,
+                              double* cost /* [N] */, int32_t* iterations /* [N] */, int32_t* exit_status /* [N] */);
+int mas_hip_get_solution_device(mas_hip_solver*, void* X_dev, void* U_dev, void* cost_dev);
+int mas_hip_total_cost(mas_hip_solver*, double* total);             /* Solution.total_cost */
+int mas_hip_get_trust_radii_host(mas_hip_solver*, double* radii /* [N] */);
+
+/* ---- staged access for parity tests: one linearisation sweep + one backward pass on the
+ * current trajectory.  derivs [N][T][ND] with ND = A,B,l_x,l_u,l_xx,l_uu,l_ux (column-major
+ * blocks), k [N][T][nu], K [N][T][nx][nu] (column-major nu x nx per step). Any may be NULL. */
+int mas_hip_debug_backward_host(mas_hip_solver*, double* derivs, double* k, double* K, int64_t* reg_events);
+
+/* ---- measurement ---- */
+typedef struct mas_hip_stats {
+  int64_t agent_iterations;      /* sum over agents of iLQR iterations since reset          */
+  int64_t converged_solves;      /* solves that exited through improvement < tolerance      */
+  int64_t solves;                /* agent-solves started                                    */
+  int64_t reg_events;            /* times reg*I was added (ilqr.hpp:180)                    */
+  int64_t batch_iterations;      /* host-loop iterations (kernel rounds)                    */
+  double  wall_ms;               /* host wall time inside run_* / solve since reset         */
+} mas_hip_stats;
+int mas_hip_get_stats(mas_hip_solver*, mas_hip_stats* out);
+int mas_hip_reset_stats(mas_hip_solver*);
+
+/* per-kernel HIP-event timing on the handle's stream (off by default) */
+typedef struct mas_hip_kernel_time {
+  char    name[48];
+  int64_t launches;
+  double  total_ms;
+  double  algorithmic_bytes;     /* summed over launches (DESIGN.md defines the per-unit figures) */
+} mas_hip_kernel_time;
+int mas_hip_set_profiling(mas_hip_solver*, int enabled);
+int mas_hip_get_kernel_times(mas_hip_solver*, mas_hip_kernel_time* out, int capacity, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAS_HIP_H */

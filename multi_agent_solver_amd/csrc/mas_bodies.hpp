@@ -1,0 +1,303 @@
+// mas_bodies.hpp -- kernel bodies of the batched iLQR path over the SoA device layout.
+//
+// Device layout: every per-agent quantity is stored "structure of arrays"
+// with the AGENT index fastest:  element (row r, agent a) of an array with R rows lives at
+// base[r * Np + a], Np = N rounded up to a multiple of 64.  A wavefront's 64 lanes are 64
+// consecutive agents, so each load/store instruction touches 64 consecutive doubles (512 B,
+// fully coalesced) without any LDS staging.  Rows are (t, component) pairs, t-major.
+//
+// Each body is a functor called with (agent) or (agent, y); y is a time step (linearisation
+// sweep, commit) or an alpha-trial index (speculative line search).
+#pragma once
+
+#include "mas_lane.hpp"
+
+namespace mas {
+
+constexpr int kNumAlphas = 10;   // alpha = 1, 1/2, ... while alpha >= 1e-3 (ilqr.hpp:199-206): 2^0 .. 2^-9
+
+enum ExitCode : int { kExitConverged = 0, kExitMaxIter = 1, kExitTime = 2, kExitNonFinite = 4 };
+
+struct Dims {
+  int N;        // agents
+  int T;        // horizon_steps
+  size_t Np;    // padded agent count (row stride)
+};
+
+#define MAS_AT(base, row, a) (base)[static_cast<size_t>(row) * d.Np + static_cast<size_t>(a)]
+
+// -------------------------------------------------------------------------------------------
+// integrate_horizon + objective (ilqr.hpp:75-78; ocp.hpp:110,182): one lane per agent.
+template <class M>
+struct RolloutCostBody {
+  Dims d; double dt; ModelParams P;
+  const double* x0;      // [nx][Np]
+  const double* U;       // [T*nu][Np]
+  double* X;             // [(T+1)*nx][Np]
+  double* cost;          // [Np]
+  double* merit;         // [Np] (current merit == objective without constraint functions, ilqr.hpp:379-407)
+  const int* active;     // optional mask
+  MAS_HD void operator()(int a) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (active && !active[a]) return;
+    double x[NX], u[NU], xn[NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(X, i, a) = x[i]; }
+    double c = 0.0;
+    for (int t = 0; t < d.T; ++t) {
+      MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = MAS_AT(U, t * NU + i, a);
+      c += M::stage_cost(x, u, t, P);
+      rk4_step<M>(x, u, dt, xn, P);
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(X, (t + 1) * NX + i, a) = x[i]; }
+    }
+    c += M::terminal_cost(x, P);
+    cost[a] = c;
+    if (merit) merit[a] = c;
+  }
+};
+
+// -------------------------------------------------------------------------------------------
+// Linearisation sweep (ilqr.hpp:106-113), one lane per (agent, t): the time steps of one
+// trajectory are independent, which the reference never exploits.  Streaming kernel:
+// reads x_t,u_t, writes the ND derivative rows of step t.
+template <class M>
+struct SweepBody {
+  Dims d; ModelParams P;
+  const double* X; const double* U;
+  double* D;             // [T*ND][Np]
+  const int* active;
+  MAS_HD void operator()(int a, int t) const {
+    using L = DerivLayout<M>;
+    constexpr int NX = M::NX, NU = M::NU;
+    if (!active[a]) return;
+    double x[NX], u[NU], Dl[L::ND];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = MAS_AT(X, t * NX + i, a);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = MAS_AT(U, t * NU + i, a);
+    linearise<M>(x, u, t, Dl, P);
+    MAS_UNROLL for (int i = 0; i < L::ND; ++i) MAS_AT(D, t * L::ND + i, a) = Dl[i];
+  }
+};
+
+// -------------------------------------------------------------------------------------------
+// Backward Riccati recursion (ilqr.hpp:92-193), one lane per agent, sequential in t.
+template <class M>
+struct BackwardBody {
+  Dims d; ModelParams P;
+  const double* X; const double* D;
+  double* kff;           // [T*nu][Np]
+  double* Kfb;           // [T*nu*nx][Np], row (t, c*NU + i) = K_t(i, c)
+  long long* reg_events; // [Np]
+  const int* active;
+  MAS_HD void operator()(int a) const {
+    using L = DerivLayout<M>;
+    constexpr int NX = M::NX, NU = M::NU;
+    if (!active[a]) return;
+    double vx[NX], vxx[NX * NX], xT[NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = MAS_AT(X, d.T * NX + i, a);
+    terminal_boundary<M>(xT, vx, vxx, P);
+    long long regs = 0;
+    for (int t = d.T - 1; t >= 0; --t) {
+      double Dl[L::ND];
+      MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = MAS_AT(D, t * L::ND + i, a);
+      QFunction<M> q;
+      assemble_q<M>(Dl, vx, vxx, q);
+      double Lfac[NU * NU], k[NU], K[NU * NX];
+      regs += llt_ladder<NU>(q.quu, Lfac);
+      gains_and_value<M>(q, Lfac, k, K, vx, vxx);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(kff, t * NU + i, a) = k[i];
+      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) MAS_AT(Kfb, t * NU * NX + i, a) = K[i];
+    }
+    reg_events[a] += regs;
+  }
+};
+
+// -------------------------------------------------------------------------------------------
+// Speculative line search (ilqr.hpp:195-228): one lane per (agent, alpha trial).  The
+// reference tries alpha = 1, 1/2, ... one after the other and stops at the first strict
+// decrease; here all ten trials roll out concurrently and SelectBody then picks the first
+// (largest) alpha that decreases the merit -- the same decision, one sequential pass deep.
+template <class M>
+struct ForwardBody {
+  Dims d; double dt; ModelParams P;
+  bool clamp; double lb[M::NU], ub[M::NU];
+  const double* x0; const double* X; const double* U; const double* kff; const double* Kfb;
+  double* Xs;            // [NA][(T+1)*nx][Np] trial trajectories
+  double* Us;            // [NA][T*nu][Np]
+  double* trial_merit;   // [NA][Np]
+  const int* active;
+  MAS_HD void operator()(int a, int j) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (!active[a]) return;
+    double alpha = 1.0;
+    for (int q = 0; q < j; ++q) alpha *= 0.5;
+    double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
+    double* Uj = Us + static_cast<size_t>(j) * d.T * NU * d.Np;
+    double x[NX], xn[NX], xr[NX], ur[NU], k[NU], K[NU * NX], u[NU];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(Xj, i, a) = x[i]; }
+    double c = 0.0;
+    for (int t = 0; t < d.T; ++t) {
+      MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = MAS_AT(X, t * NX + i, a);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) ur[i] = MAS_AT(U, t * NU + i, a);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) k[i] = MAS_AT(kff, t * NU + i, a);
+      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = MAS_AT(Kfb, t * NU * NX + i, a);
+      forward_control<M>(x, xr, ur, k, K, alpha, clamp, lb, ub, u);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(Uj, t * NU + i, a) = u[i];
+      c += M::stage_cost(x, u, t, P);
+      rk4_step<M>(x, u, dt, xn, P);
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(Xj, (t + 1) * NX + i, a) = x[i]; }
+    }
+    c += M::terminal_cost(x, P);
+    trial_merit[static_cast<size_t>(j) * d.Np + a] = c;
+  }
+};
+
+// -------------------------------------------------------------------------------------------
+// Per-agent acceptance + termination bookkeeping (ilqr.hpp:219-234,269-271).
+struct SelectBody {
+  Dims d; double tolerance; int max_iterations;
+  const double* trial_merit;  // [NA][Np]
+  double* cost; double* merit;
+  int* active; int* alpha_sel; int* iters_solve; int* iters_total; int* exit_code;
+  int* n_active;              // counter of agents still active after this iteration
+  long long* n_converged;
+  MAS_HD void operator()(int a) const {
+    if (!active[a]) { alpha_sel[a] = -1; return; }
+    const double cur = merit[a];
+    int sel = -1; double best = cur;
+    for (int j = 0; j < kNumAlphas; ++j) {
+      const double m = trial_merit[static_cast<size_t>(j) * d.Np + a];
+      if (m < best) { best = m; sel = j; break; }          // first strict decrease, ilqr.hpp:220-226
+    }
+    const double improvement = cur - best;                  // 0 when no trial was accepted
+    alpha_sel[a] = sel;
+    if (sel >= 0) { cost[a] = best; merit[a] = best; }      // cost == objective(best_x,best_u) == accepted merit
+    const int it = iters_solve[a] + 1;
+    iters_solve[a] = it; iters_total[a] += 1;
+    if (improvement < tolerance) {                          // ilqr.hpp:269-271
+      active[a] = 0; exit_code[a] = kExitConverged | (std::isfinite(best) ? 0 : kExitNonFinite);
+      MAS_ATOMIC_ADD_I64(n_converged, 1LL);
+    } else if (it >= max_iterations) {                      // ilqr.hpp:82
+      active[a] = 0; exit_code[a] = kExitMaxIter | (std::isfinite(best) ? 0 : kExitNonFinite);
+    } else {
+      MAS_ATOMIC_ADD_INT(n_active, 1);
+    }
+  }
+};
+
+// copy the accepted trial into the current trajectory (x = best_x; u = best_u, ilqr.hpp:231-232)
+template <class M>
+struct CommitBody {
+  Dims d;
+  const double* Xs; const double* Us; const int* alpha_sel;
+  double* X; double* U;
+  MAS_HD void operator()(int a, int t) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int j = alpha_sel[a];
+    if (j < 0) return;
+    const double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
+    const double* Uj = Us + static_cast<size_t>(j) * d.T * NU * d.Np;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(X, t * NX + i, a) = MAS_AT(Xj, t * NX + i, a);
+    if (t < d.T) { MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(U, t * NU + i, a) = MAS_AT(Uj, t * NU + i, a); }
+  }
+};
+
+// start of a solve: every agent active, per-solve iteration counter cleared (resize_buffers
+// zeroes the gains, ilqr.hpp:292-293; they are rewritten before use so nothing to clear here)
+struct BeginSolveBody {
+  int* active; int* iters_solve; int* exit_code; int* alpha_sel;
+  MAS_HD void operator()(int a) const { active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1; }
+};
+
+struct MarkTimeoutBody {
+  int* active; int* exit_code;
+  MAS_HD void operator()(int a) const { if (active[a]) { active[a] = 0; exit_code[a] = kExitTime; } }
+};
+
+// -------------------------------------------------------------------------------------------
+// Trust-region epilogue, nash.hpp:214-243, one lane per agent.
+template <class M>
+struct TrustRegionBody {
+  Dims d; double dt; ModelParams P;
+  const double* x0;
+  double* X; double* U; double* cost;               // candidate in, accepted/reverted out
+  const double* X_old; const double* U_old; const double* cost_old;
+  double* radii;
+  MAS_HD void operator()(int a) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    const double radius = radii[a];
+    double ss = 0.0;                                   // delta.norm(): Frobenius, column-major order
+    for (int r = 0; r < d.T * NU; ++r) { const double dl = MAS_AT(U, r, a) - MAS_AT(U_old, r, a); ss += dl * dl; }
+    const double norm = sqrt(ss);
+    double cand_cost = cost[a];
+    if (norm > radius) {                               // scale the step back onto the trust region, re-roll, re-cost
+      const double scale = radius / norm;
+      double x[NX], xn[NX], u[NU];
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(X, i, a) = x[i]; }
+      double c = 0.0;
+      for (int t = 0; t < d.T; ++t) {
+        MAS_UNROLL for (int i = 0; i < NU; ++i) {
+          const double uo = MAS_AT(U_old, t * NU + i, a);
+          u[i] = uo + scale * (MAS_AT(U, t * NU + i, a) - uo);
+          MAS_AT(U, t * NU + i, a) = u[i];
+        }
+        c += M::stage_cost(x, u, t, P);
+        rk4_step<M>(x, u, dt, xn, P);
+        MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(X, (t + 1) * NX + i, a) = x[i]; }
+      }
+      c += M::terminal_cost(x, P);
+      cand_cost = c;
+    }
+    if (cand_cost < cost_old[a]) {
+      cost[a] = cand_cost; radii[a] = radius * 1.5;
+    } else {
+      for (int r = 0; r < d.T * NU; ++r) MAS_AT(U, r, a) = MAS_AT(U_old, r, a);
+      for (int r = 0; r < (d.T + 1) * NX; ++r) MAS_AT(X, r, a) = MAS_AT(X_old, r, a);
+      cost[a] = cost_old[a]; radii[a] = radius * 0.5;
+    }
+  }
+};
+
+// Nash line-search blend, nash.hpp:134-142: U_trial = U_old + alpha (U_cand - U_old), roll out, cost
+template <class M>
+struct BlendRolloutBody {
+  Dims d; double dt; double alpha; ModelParams P;
+  const double* x0; const double* U_old; const double* U_cand;
+  double* X_trial; double* U_trial; double* cost_trial;
+  MAS_HD void operator()(int a) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    double x[NX], xn[NX], u[NU];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(X_trial, i, a) = x[i]; }
+    double c = 0.0;
+    for (int t = 0; t < d.T; ++t) {
+      MAS_UNROLL for (int i = 0; i < NU; ++i) {
+        const double uo = MAS_AT(U_old, t * NU + i, a);
+        u[i] = uo + alpha * (MAS_AT(U_cand, t * NU + i, a) - uo);
+        MAS_AT(U_trial, t * NU + i, a) = u[i];
+      }
+      c += M::stage_cost(x, u, t, P);
+      rk4_step<M>(x, u, dt, xn, P);
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(X_trial, (t + 1) * NX + i, a) = x[i]; }
+    }
+    c += M::terminal_cost(x, P);
+    cost_trial[a] = c;
+  }
+};
+
+// -------------------------------------------------------------------------------------------
+// layout conversion between the reference layout at the ABI ([N][cols][rows], one Eigen column
+// per time step) and the SoA device layout ([cols*rows][Np]); y = column (time step)
+struct AosToSoaBody {
+  Dims d; int rows;
+  const double* aos; double* soa; int cols;
+  MAS_HD void operator()(int a, int c) const {
+    for (int r = 0; r < rows; ++r) MAS_AT(soa, c * rows + r, a) = aos[(static_cast<size_t>(a) * cols + c) * rows + r];
+  }
+};
+struct SoaToAosBody {
+  Dims d; int rows;
+  const double* soa; double* aos; int cols;
+  MAS_HD void operator()(int a, int c) const {
+    for (int r = 0; r < rows; ++r) aos[(static_cast<size_t>(a) * cols + c) * rows + r] = MAS_AT(soa, c * rows + r, a);
+  }
+};
+
+}  // namespace mas

@@ -1,0 +1,167 @@
+// mas_capi.hip -- extern "C" boundary of libmas_hip.so (declared in include/mas_hip.h).
+//
+// Every entry point catches C++ exceptions and turns them into integer status codes; the
+// message is kept on the handle (mas_hip_last_error).  Without a HIP device create() fails
+// with MAS_HIP_ERR_NO_DEVICE -- there is no CPU fallback in the product.
+#include "../../include/mas_hip.h"
+
+#include <cstring>
+#include <new>
+
+#include "mas_solver.hpp"
+
+struct mas_hip_solver {
+  std::unique_ptr<mas::SolverBase> impl;
+  int N = 0, T = 0;
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+template <class Fn>
+int guarded(mas_hip_solver* h, Fn&& fn) {
+  if (!h || !h->impl) return MAS_HIP_ERR_INVALID;
+  try {
+    fn(*h->impl);
+    return MAS_HIP_OK;
+  } catch (const std::invalid_argument& e) {
+    h->impl->last_error = e.what();
+    return MAS_HIP_ERR_INVALID;
+  } catch (const std::logic_error& e) {
+    h->impl->last_error = e.what();
+    return MAS_HIP_ERR_STATE;
+  } catch (const std::exception& e) {
+    h->impl->last_error = e.what();
+    return MAS_HIP_ERR_RUNTIME;
+  } catch (...) {
+    h->impl->last_error = "unknown exception";
+    return MAS_HIP_ERR_RUNTIME;
+  }
+}
+
+int create_impl(const mas_hip_problem_desc* desc, void* stream, mas_hip_solver** out) {
+  if (!desc || !out) { g_create_error = "null argument"; return MAS_HIP_ERR_INVALID; }
+  *out = nullptr;
+  int nx = 0, nu = 0;
+  if (!mas::model_dims(desc->model_id, &nx, &nu)) { g_create_error = "unknown model id"; return MAS_HIP_ERR_INVALID; }
+  if (desc->n_agents < 1 || desc->horizon_steps < 1 || !(desc->dt > 0.0)) { g_create_error = "n_agents, horizon_steps and dt must be positive"; return MAS_HIP_ERR_INVALID; }
+  if ((desc->input_lower_bounds == nullptr) != (desc->input_upper_bounds == nullptr)) { g_create_error = "input bounds must be given as a pair"; return MAS_HIP_ERR_INVALID; }
+  const int ndev = mas::Backend::device_count();
+  if (ndev <= 0) { g_create_error = "no HIP device visible: libmas_hip has no CPU fallback"; return MAS_HIP_ERR_NO_DEVICE; }
+  if (desc->device < 0 || desc->device >= ndev) { g_create_error = "device ordinal out of range"; return MAS_HIP_ERR_INVALID; }
+  mas::ProblemDesc pd;
+  pd.model_id = desc->model_id; pd.n_agents = desc->n_agents; pd.horizon_steps = desc->horizon_steps; pd.device = desc->device; pd.dt = desc->dt;
+  if (desc->params) { pd.has_params = true; std::memcpy(pd.params, desc->params, sizeof(double) * 16); }
+  if (desc->input_lower_bounds) { pd.has_bounds = true; for (int i = 0; i < nu; ++i) { pd.lb[i] = desc->input_lower_bounds[i]; pd.ub[i] = desc->input_upper_bounds[i]; } }
+  pd.no_bounds = desc->no_input_bounds != 0;
+  try {
+    auto h = new mas_hip_solver();
+    h->impl = mas::make_solver(pd, stream);
+    h->N = desc->n_agents; h->T = desc->horizon_steps;
+    *out = h;
+    return MAS_HIP_OK;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return MAS_HIP_ERR_RUNTIME;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mas_hip_abi_version(void) { return MAS_HIP_ABI_VERSION; }
+int mas_hip_device_count(void) { return mas::Backend::device_count(); }
+int mas_hip_model_dims(int model_id, int* nx, int* nu) { return mas::model_dims(model_id, nx, nu) ? MAS_HIP_OK : MAS_HIP_ERR_INVALID; }
+int mas_hip_model_default_params(int model_id, int horizon_steps, double* params16) {
+  if (!params16 || !mas::model_dims(model_id, nullptr, nullptr)) return MAS_HIP_ERR_INVALID;
+  mas::model_default_params(model_id, horizon_steps, params16);
+  return MAS_HIP_OK;
+}
+int mas_hip_create(const mas_hip_problem_desc* desc, mas_hip_solver** out) { return create_impl(desc, nullptr, out); }
+int mas_hip_create_on_stream(const mas_hip_problem_desc* desc, void* hip_stream, mas_hip_solver** out) { return create_impl(desc, hip_stream, out); }
+int mas_hip_destroy(mas_hip_solver* h) {
+  if (!h) return MAS_HIP_ERR_INVALID;
+  delete h;
+  return MAS_HIP_OK;
+}
+const char* mas_hip_last_error(const mas_hip_solver* h) { return (h && h->impl) ? h->impl->last_error.c_str() : g_create_error.c_str(); }
+
+int mas_hip_set_param(mas_hip_solver* h, const char* key, double value) {
+  if (!key) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) { s.set_param(key, value); });
+}
+int mas_hip_check_params(const mas_hip_solver* h) {
+  if (!h || !h->impl) return MAS_HIP_ERR_INVALID;
+  if (!h->impl->params_complete()) { h->impl->last_error = "SolverParams lacks max_iterations, tolerance or max_ms (iLQR::set_params uses params.at())"; return MAS_HIP_ERR_INVALID; }
+  return MAS_HIP_OK;
+}
+
+int mas_hip_set_initial_states_host(mas_hip_solver* h, const double* x0) {
+  if (!x0) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) { s.set_initial_states(x0, false); });
+}
+int mas_hip_set_controls_host(mas_hip_solver* h, const double* U) { return guarded(h, [&](mas::SolverBase& s) { s.set_controls(U, false); }); }
+int mas_hip_set_initial_states_device(mas_hip_solver* h, const void* x0) {
+  if (!x0) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) { s.set_initial_states(static_cast<const double*>(x0), true); });
+}
+int mas_hip_set_controls_device(mas_hip_solver* h, const void* U) { return guarded(h, [&](mas::SolverBase& s) { s.set_controls(static_cast<const double*>(U), true); }); }
+int mas_hip_initialize_problem(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.initialize_problem(); s.be.sync(); }); }
+int mas_hip_save_initial(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.save_initial(); s.be.sync(); }); }
+int mas_hip_restore_initial(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.restore_initial(); s.be.sync(); }); }
+
+int mas_hip_solve(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.solve(); }); }
+int mas_hip_run_sequential(mas_hip_solver* h, int max_outer) { return guarded(h, [&](mas::SolverBase& s) { s.run_sequential(max_outer); }); }
+int mas_hip_run_trust_region(mas_hip_solver* h, int max_outer) { return guarded(h, [&](mas::SolverBase& s) { s.run_trust_region(max_outer); }); }
+int mas_hip_run_line_search(mas_hip_solver* h, int max_outer) { return guarded(h, [&](mas::SolverBase& s) { s.run_line_search(max_outer); }); }
+int mas_hip_run_centralized(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.run_centralized(); }); }
+
+int mas_hip_get_solution_host(mas_hip_solver* h, double* X, double* U, double* cost, int32_t* iterations, int32_t* exit_status) {
+  return guarded(h, [&](mas::SolverBase& s) { s.get_solution(X, U, cost, iterations, exit_status, false); });
+}
+int mas_hip_get_solution_device(mas_hip_solver* h, void* X, void* U, void* cost) {
+  return guarded(h, [&](mas::SolverBase& s) { s.get_solution(static_cast<double*>(X), static_cast<double*>(U), static_cast<double*>(cost), nullptr, nullptr, true); });
+}
+int mas_hip_total_cost(mas_hip_solver* h, double* total) {
+  if (!total) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) { *total = s.total_cost(); });
+}
+int mas_hip_get_trust_radii_host(mas_hip_solver* h, double* radii) {
+  if (!radii) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) { s.get_trust_radii(radii); });
+}
+int mas_hip_debug_backward_host(mas_hip_solver* h, double* derivs, double* k, double* K, int64_t* reg_events) {
+  return guarded(h, [&](mas::SolverBase& s) { s.debug_backward(derivs, k, K, reg_events); });
+}
+
+int mas_hip_get_stats(mas_hip_solver* h, mas_hip_stats* out) {
+  if (!out) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) {
+    const mas::HostStats st = s.get_stats();
+    out->agent_iterations = st.agent_iterations; out->converged_solves = st.converged_solves; out->solves = st.solves;
+    out->reg_events = st.reg_events; out->batch_iterations = st.batch_iterations; out->wall_ms = st.wall_ms;
+  });
+}
+int mas_hip_reset_stats(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.reset_stats(); s.be.stats.clear(); }); }
+
+int mas_hip_set_profiling(mas_hip_solver* h, int enabled) {
+  return guarded(h, [&](mas::SolverBase& s) { s.be.resolve_profile(); s.be.profiling = enabled != 0; });
+}
+int mas_hip_get_kernel_times(mas_hip_solver* h, mas_hip_kernel_time* out, int capacity, int* count) {
+  if (!count) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) {
+    s.be.resolve_profile();
+    int n = 0;
+    for (const auto& kv : s.be.stats) {
+      if (out && n < capacity) {
+        std::memset(&out[n], 0, sizeof(out[n]));
+        std::strncpy(out[n].name, kv.first.c_str(), sizeof(out[n].name) - 1);
+        out[n].launches = kv.second.launches; out[n].total_ms = kv.second.total_ms; out[n].algorithmic_bytes = kv.second.algorithmic_bytes;
+      }
+      ++n;
+    }
+    *count = n;
+  });
+}
+
+}  // extern "C"

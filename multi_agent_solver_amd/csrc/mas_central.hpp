@@ -1,0 +1,165 @@
+// mas_central.hpp -- the centralised strategy as block-diagonal batched work.
+//
+// CentralizedStrategy (strategies/centralized.hpp:18-38) stacks all agents into one OCP
+// (multi_agent_problem.hpp:52-127) and runs ONE iLQR on it.  The stacked dynamics Jacobians
+// are exactly block-diagonal and the stacked cost Hessians are block-diagonal up to finite-
+// difference noise, so the solve is carried out per agent block -- but three things stay
+// shared by all agents, as they are in the stacked solve:
+//   * the step length alpha and its acceptance (merit = sum of all agents' costs),
+//   * termination (improvement of that merit),
+//   * the regularisation ladder: LLT of the block-diagonal q_uu fails if ANY block fails, and
+//     reg*I is then added to EVERY block (ilqr.hpp:172-182).
+// The ladder needs an any-agent reduction per time step, so the backward pass runs as ONE
+// workgroup (<= 1024 agents = 16 wavefronts) with a barrier-reduction per rung.
+#pragma once
+
+#include "mas_bodies.hpp"
+
+namespace mas {
+
+constexpr int kCentralMaxAgents = 1024;
+
+struct CentralState {
+  double cur_total;     // current merit of the stacked problem
+  double improvement;
+  int j_sel;            // accepted alpha index of the last iteration, -1 if none
+  int done;             // improvement < tolerance
+  int iterations;
+  int pad;
+};
+
+// serial sum in agent order (the stacked objective adds the blocks in block order)
+struct CentralInitBody {
+  Dims d; const double* cost; CentralState* st;
+#if defined(MAS_HOST_EMULATION)
+  void run_serial(int n) const {
+    double s = 0.0; for (int a = 0; a < n; ++a) s += cost[a];
+    st->cur_total = s; st->improvement = 0.0; st->j_sel = -1; st->done = 0; st->iterations = 0;
+  }
+#else
+  __device__ void run_block(int n) const {
+    if (threadIdx.x == 0) {
+      double s = 0.0; for (int a = 0; a < n; ++a) s += cost[a];
+      st->cur_total = s; st->improvement = 0.0; st->j_sel = -1; st->done = 0; st->iterations = 0;
+    }
+  }
+#endif
+};
+
+template <class M>
+struct CentralBackwardBody {
+  Dims d; ModelParams P;
+  const double* X; const double* D;
+  double* kff; double* Kfb; long long* reg_events;
+
+  struct AgentState { double vx[M::NX], vxx[M::NX * M::NX]; };
+
+  MAS_HD void begin(int a, AgentState& s) const {
+    constexpr int NX = M::NX;
+    double xT[NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = MAS_AT(X, d.T * NX + i, a);
+    terminal_boundary<M>(xT, s.vx, s.vxx, P);
+  }
+  MAS_HD void assemble(int a, int t, const AgentState& s, QFunction<M>& q) const {
+    using L = DerivLayout<M>;
+    double Dl[L::ND];
+    MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = MAS_AT(D, t * L::ND + i, a);
+    assemble_q<M>(Dl, s.vx, s.vxx, q);
+  }
+  MAS_HD void finish(int a, int t, const QFunction<M>& q, const double* Lfac, AgentState& s) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    double k[NU], K[NU * NX];
+    gains_and_value<M>(q, Lfac, k, K, s.vx, s.vxx);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(kff, t * NU + i, a) = k[i];
+    MAS_UNROLL for (int i = 0; i < NU * NX; ++i) MAS_AT(Kfb, t * NU * NX + i, a) = K[i];
+  }
+
+#if defined(MAS_HOST_EMULATION)
+  void run_serial(int n) const {
+    constexpr int NU = M::NU;
+    std::vector<AgentState> st(n); std::vector<QFunction<M>> q(n);
+    std::vector<double> cur(static_cast<size_t>(n) * NU * NU), Lf(static_cast<size_t>(n) * NU * NU);
+    for (int a = 0; a < n; ++a) begin(a, st[a]);
+    long long regs = 0;
+    for (int t = d.T - 1; t >= 0; --t) {
+      for (int a = 0; a < n; ++a) { assemble(a, t, st[a], q[a]); for (int i = 0; i < NU * NU; ++i) cur[a * NU * NU + i] = q[a].quu[i]; }
+      double reg = 1e-6; int rungs = 0;
+      for (;;) {
+        int any = 0;
+        for (int a = 0; a < n; ++a) { for (int i = 0; i < NU * NU; ++i) Lf[a * NU * NU + i] = cur[a * NU * NU + i]; any |= llt_compute<NU>(&Lf[a * NU * NU]); }
+        if (!any || rungs >= kRegLadderMax) break;
+        for (int a = 0; a < n; ++a) for (int i = 0; i < NU; ++i) cur[a * NU * NU + i * NU + i] += reg;
+        reg *= 10.0; ++rungs;
+      }
+      regs += rungs;
+      for (int a = 0; a < n; ++a) finish(a, t, q[a], &Lf[a * NU * NU], st[a]);
+    }
+    reg_events[0] += regs;
+  }
+#else
+  __device__ void run_block(int n) const {
+    constexpr int NU = M::NU;
+    const int a = threadIdx.x;
+    const bool valid = a < n;
+    AgentState s; QFunction<M> q;
+    if (valid) begin(a, s);
+    long long regs = 0;
+    for (int t = d.T - 1; t >= 0; --t) {
+      double cur[NU * NU], Lf[NU * NU];
+      if (valid) { assemble(a, t, s, q); MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = q.quu[i]; }
+      double reg = 1e-6; int rungs = 0;
+      for (;;) {                                        // every thread of the block takes the same trips
+        int fail = 0;
+        if (valid) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lf[i] = cur[i]; fail = llt_compute<NU>(Lf); }
+        const int any = __syncthreads_or(fail);
+        if (!any || rungs >= kRegLadderMax) break;
+        if (valid) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; }
+        reg *= 10.0; ++rungs;
+      }
+      regs += rungs;
+      if (valid) finish(a, t, q, Lf, s);
+    }
+    if (a == 0) reg_events[0] += regs;
+  }
+#endif
+};
+
+// merit of every alpha trial = serial sum over agents; first strict decrease wins for ALL agents
+// (ilqr.hpp:219-226 on the stacked problem); termination ilqr.hpp:269-271.
+struct CentralSelectBody {
+  Dims d; double tolerance;
+  const double* trial_merit; double* cost; double* merit; int* alpha_sel; int* iters_total; CentralState* st;
+
+  MAS_HD static void decide(const double* sums, double tolerance, CentralState* st) {
+    const double cur = st->cur_total;
+    int sel = -1; double best = cur;
+    for (int j = 0; j < kNumAlphas; ++j) if (sums[j] < best) { best = sums[j]; sel = j; break; }
+    st->improvement = cur - best; st->cur_total = best; st->j_sel = sel; st->iterations += 1;
+    st->done = (st->improvement < tolerance) ? 1 : 0;
+  }
+  MAS_HD void apply(int a, int sel) const {
+    alpha_sel[a] = sel; iters_total[a] += 1;
+    if (sel >= 0) { const double m = trial_merit[static_cast<size_t>(sel) * d.Np + a]; cost[a] = m; merit[a] = m; }
+  }
+#if defined(MAS_HOST_EMULATION)
+  void run_serial(int n) const {
+    double sums[kNumAlphas];
+    for (int j = 0; j < kNumAlphas; ++j) { double s = 0.0; for (int a = 0; a < n; ++a) s += trial_merit[static_cast<size_t>(j) * d.Np + a]; sums[j] = s; }
+    decide(sums, tolerance, st);
+    for (int a = 0; a < n; ++a) apply(a, st->j_sel);
+  }
+#else
+  __device__ void run_block(int n) const {
+    __shared__ double sums[kNumAlphas];
+    __shared__ int sel_sh;
+    const int tid = threadIdx.x;
+    if (tid < kNumAlphas) { double s = 0.0; for (int a = 0; a < n; ++a) s += trial_merit[static_cast<size_t>(tid) * d.Np + a]; sums[tid] = s; }
+    __syncthreads();
+    if (tid == 0) { decide(sums, tolerance, st); sel_sh = st->j_sel; }
+    __syncthreads();
+    if (tid < n) apply(tid, sel_sh);
+  }
+#endif
+};
+
+}  // namespace mas

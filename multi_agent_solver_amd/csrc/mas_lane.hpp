@@ -1,0 +1,393 @@
+// mas_lane.hpp -- per-lane FP64 math of the batched iLQR path.
+//
+// One "lane" owns one agent (or one agent x time step, or one agent x alpha trial); all state
+// lives in registers as small fixed-size arrays indexed by compile-time constants after full
+// unrolling.  Each function restates one piece of the reference and keeps the reference's
+// operation order so results agree with a scalar CPU evaluation to the last bit wherever the
+// math library agrees (sin/cos/tan differ by <= a few ulp between glibc and ROCm's ocml).
+#pragma once
+
+#include "mas_models.hpp"
+
+namespace mas {
+
+// ------------------------------------------------------------------ small helpers ------
+// v with component i replaced by v[i] + se.  Eigen adds a whole vector (x + dx) so untouched
+// components see "+ 0.0"; that only differs for -0.0, which none of the models can observe.
+template <int N>
+MAS_HD void perturb1(const double* v, int i, double se, double* out) {
+  MAS_UNROLL for (int k = 0; k < N; ++k) out[k] = (k == i) ? v[k] + se : v[k];
+}
+template <int N>
+MAS_HD void perturb2(const double* v, int i, double si, int j, double sj, double* out) {
+  MAS_UNROLL for (int k = 0; k < N; ++k) {
+    const double w = (k == i) ? v[k] + si : v[k];
+    out[k] = (k == j) ? w + sj : w;
+  }
+}
+MAS_HD double safe_value(double v) { return std::isfinite(v) ? v : 0.0; }   // finite_differences.hpp:95-107
+
+// integrate_rk4, integrator.hpp:19-28
+template <class M>
+MAS_HD void rk4_step(const double* x, const double* u, double dt, double* out, const ModelParams& P) {
+  constexpr int NX = M::NX;
+  double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
+  M::dynamics(x, u, k1, P);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + (0.5 * dt) * k1[i];
+  M::dynamics(xs, u, k2, P);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + (0.5 * dt) * k2[i];
+  M::dynamics(xs, u, k3, P);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + dt * k3[i];
+  M::dynamics(xs, u, k4, P);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) out[i] = x[i] + (dt / 6.0) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+}
+
+// clamp_controls on one column, constraint_helpers.hpp:107-114: cwiseMin(upper).cwiseMax(lower)
+template <int NU>
+MAS_HD void clamp_column(double* u, const double* lb, const double* ub) {
+  MAS_UNROLL for (int i = 0; i < NU; ++i) {
+    double v = u[i];
+    v = (ub[i] < v) ? ub[i] : v;
+    v = (v < lb[i]) ? lb[i] : v;
+    u[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ linearisation ------
+// One (agent, t): ilqr.hpp:106-113 through the hooks OCP::initialize_problem installs
+// (ocp.hpp:117-135): central differences of finite_differences.hpp:53-287 unless the
+// workload's example wires an analytic hook.  D is laid out as DerivLayout<M>.
+template <class M>
+MAS_HD void linearise(const double* x, const double* u, int t, double* D, const ModelParams& P) {
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU;
+  double xp[NX], xm[NX], up[NU], um[NU], fp[NX], fm[NX];
+
+  if constexpr (M::kAnalyticA) {
+    M::A(x, u, D + L::oA, P);
+  } else {                                              // finite_differences.hpp:53-71, eps = 1e-6
+    const double eps = 1e-6;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      perturb1<NX>(x, i, +eps, xp); M::dynamics(xp, u, fp, P);
+      perturb1<NX>(x, i, -eps, xm); M::dynamics(xm, u, fm, P);
+      MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oA + i * NX + r] = (fp[r] - fm[r]) / (2 * eps);
+    }
+  }
+  if constexpr (M::kAnalyticB) {
+    M::B(x, u, D + L::oB, P);
+  } else {                                              // :73-92
+    const double eps = 1e-6;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      perturb1<NU>(u, i, +eps, up); M::dynamics(x, up, fp, P);
+      perturb1<NU>(u, i, -eps, um); M::dynamics(x, um, fm, P);
+      MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oB + i * NX + r] = (fp[r] - fm[r]) / (2 * eps);
+    }
+  }
+  if constexpr (M::kAnalyticLx) {
+    M::lx(x, u, t, D + L::oLx, P);
+  } else {                                              // :110-122 (no safe_eval on gradients)
+    const double eps = 1e-6;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      perturb1<NX>(x, i, +eps, xp); perturb1<NX>(x, i, -eps, xm);
+      D[L::oLx + i] = (M::stage_cost(xp, u, t, P) - M::stage_cost(xm, u, t, P)) / (2 * eps);
+    }
+  }
+  if constexpr (M::kAnalyticLu) {
+    M::lu(x, u, t, D + L::oLu, P);
+  } else {                                              // :124-136
+    const double eps = 1e-6;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      perturb1<NU>(u, i, +eps, up); perturb1<NU>(u, i, -eps, um);
+      D[L::oLu + i] = (M::stage_cost(x, up, t, P) - M::stage_cost(x, um, t, P)) / (2 * eps);
+    }
+  }
+  if constexpr (M::kAnalyticLxx) {
+    M::lxx(x, u, t, D + L::oLxx, P);
+  } else {                                              // :138-173, eps = 1e-5, (i,j) and (j,i) separately
+    const double eps = 1e-5;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      perturb1<NX>(x, i, +eps, xp); perturb1<NX>(x, i, -eps, xm);
+      const double f_plus = safe_value(M::stage_cost(xp, u, t, P));
+      const double f = safe_value(M::stage_cost(x, u, t, P));
+      const double f_minus = safe_value(M::stage_cost(xm, u, t, P));
+      D[L::oLxx + i * NX + i] = (f_plus - 2 * f + f_minus) / (eps * eps);
+    }
+    MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      MAS_UNROLL for (int j = 0; j < NX; ++j) {
+        if (i != j) {
+          perturb2<NX>(x, i, +eps, j, +eps, xp); const double f_pp = safe_value(M::stage_cost(xp, u, t, P));
+          perturb2<NX>(x, i, +eps, j, -eps, xp); const double f_pm = safe_value(M::stage_cost(xp, u, t, P));
+          perturb2<NX>(x, i, -eps, j, +eps, xp); const double f_mp = safe_value(M::stage_cost(xp, u, t, P));
+          perturb2<NX>(x, i, -eps, j, -eps, xp); const double f_mm = safe_value(M::stage_cost(xp, u, t, P));
+          D[L::oLxx + j * NX + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+        }
+      }
+    }
+  }
+  if constexpr (M::kAnalyticLuu) {
+    M::luu(x, u, t, D + L::oLuu, P);
+  } else {                                              // :175-210
+    const double eps = 1e-5;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      perturb1<NU>(u, i, +eps, up); perturb1<NU>(u, i, -eps, um);
+      const double f_plus = safe_value(M::stage_cost(x, up, t, P));
+      const double f = safe_value(M::stage_cost(x, u, t, P));
+      const double f_minus = safe_value(M::stage_cost(x, um, t, P));
+      D[L::oLuu + i * NU + i] = (f_plus - 2 * f + f_minus) / (eps * eps);
+    }
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      MAS_UNROLL for (int j = 0; j < NU; ++j) {
+        if (i != j) {
+          perturb2<NU>(u, i, +eps, j, +eps, up); const double f_pp = safe_value(M::stage_cost(x, up, t, P));
+          perturb2<NU>(u, i, +eps, j, -eps, up); const double f_pm = safe_value(M::stage_cost(x, up, t, P));
+          perturb2<NU>(u, i, -eps, j, +eps, up); const double f_mp = safe_value(M::stage_cost(x, up, t, P));
+          perturb2<NU>(u, i, -eps, j, -eps, up); const double f_mm = safe_value(M::stage_cost(x, up, t, P));
+          D[L::oLuu + j * NU + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+        }
+      }
+    }
+  }
+  if constexpr (M::kAnalyticLux) {
+    M::lux(x, u, t, D + L::oLux, P);
+  } else {                                              // :263-287, eps = 1e-6, H is nu x nx
+    const double eps = 1e-6;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      MAS_UNROLL for (int j = 0; j < NX; ++j) {
+        perturb1<NU>(u, i, +eps, up); perturb1<NU>(u, i, -eps, um);
+        perturb1<NX>(x, j, +eps, xp); perturb1<NX>(x, j, -eps, xm);
+        const double f_pp = safe_value(M::stage_cost(xp, up, t, P));
+        const double f_pm = safe_value(M::stage_cost(xm, up, t, P));
+        const double f_mp = safe_value(M::stage_cost(xp, um, t, P));
+        const double f_mm = safe_value(M::stage_cost(xm, um, t, P));
+        D[L::oLux + j * NU + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+      }
+    }
+  }
+}
+
+// in-place  V = 0.5 * (V + V^T)  in the order Eigen executes the reference's aliased
+// statement (ilqr.hpp:102,192): scalar column-major traversal without a temporary, so the
+// lower entry is averaged from old values and the mirrored upper entry then reads the
+// already-updated lower one.
+template <int N>
+MAS_HD void symmetrise_inplace(double* V) {
+  MAS_UNROLL for (int j = 0; j < N; ++j) {
+    MAS_UNROLL for (int i = 0; i < N; ++i) V[j * N + i] = 0.5 * (V[j * N + i] + V[i * N + j]);
+  }
+}
+
+// terminal boundary condition, ilqr.hpp:92-102
+template <class M>
+MAS_HD void terminal_boundary(const double* xT, double* vx, double* vxx, const ModelParams& P) {
+  constexpr int NX = M::NX;
+  if constexpr (M::kAnalyticTerm) {
+    M::term_grad(xT, vx, P);
+    M::term_hess(xT, vxx, P);
+  } else if constexpr (M::kZeroTerminal) {
+    // FD of an identically-zero terminal cost is exactly zero: (0-0)/(2 eps), (0-2*0+0)/eps^2
+    MAS_UNROLL for (int i = 0; i < NX; ++i) vx[i] = 0.0;
+    MAS_UNROLL for (int i = 0; i < NX * NX; ++i) vxx[i] = 0.0;
+  } else {
+    double xp[NX], xm[NX];
+    {                                                   // finite_differences.hpp:212-224
+      const double eps = 1e-6;
+      MAS_UNROLL for (int i = 0; i < NX; ++i) {
+        perturb1<NX>(xT, i, +eps, xp); perturb1<NX>(xT, i, -eps, xm);
+        vx[i] = (M::terminal_cost(xp, P) - M::terminal_cost(xm, P)) / (2 * eps);
+      }
+    }
+    {                                                   // :226-261
+      const double eps = 1e-5;
+      MAS_UNROLL for (int i = 0; i < NX; ++i) {
+        perturb1<NX>(xT, i, +eps, xp); perturb1<NX>(xT, i, -eps, xm);
+        const double f_plus = safe_value(M::terminal_cost(xp, P));
+        const double f = safe_value(M::terminal_cost(xT, P));
+        const double f_minus = safe_value(M::terminal_cost(xm, P));
+        vxx[i * NX + i] = (f_plus - 2 * f + f_minus) / (eps * eps);
+      }
+      MAS_UNROLL for (int i = 0; i < NX; ++i) {
+        MAS_UNROLL for (int j = 0; j < NX; ++j) {
+          if (i != j) {
+            perturb2<NX>(xT, i, +eps, j, +eps, xp); const double f_pp = safe_value(M::terminal_cost(xp, P));
+            perturb2<NX>(xT, i, +eps, j, -eps, xp); const double f_pm = safe_value(M::terminal_cost(xp, P));
+            perturb2<NX>(xT, i, -eps, j, +eps, xp); const double f_mp = safe_value(M::terminal_cost(xp, P));
+            perturb2<NX>(xT, i, -eps, j, -eps, xp); const double f_mm = safe_value(M::terminal_cost(xp, P));
+            vxx[j * NX + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+          }
+        }
+      }
+    }
+  }
+  symmetrise_inplace<NX>(vxx);
+}
+
+// ------------------------------------------------------------------ backward step ------
+// C(m x n) = A^T B with A stored p x m, B stored p x n (column-major), sums in k order from 0.0
+template <int P_, int M_, int N_>
+MAS_HD void mat_AtB(const double* A, const double* B, double* C) {
+  MAS_UNROLL for (int j = 0; j < N_; ++j) {
+    MAS_UNROLL for (int i = 0; i < M_; ++i) {
+      double s = 0.0;
+      MAS_UNROLL for (int k = 0; k < P_; ++k) s += A[i * P_ + k] * B[j * P_ + k];
+      C[j * M_ + i] = s;
+    }
+  }
+}
+// C(m x n) = A(m x p) B(p x n)
+template <int M_, int P_, int N_>
+MAS_HD void mat_AB(const double* A, const double* B, double* C) {
+  MAS_UNROLL for (int j = 0; j < N_; ++j) {
+    MAS_UNROLL for (int i = 0; i < M_; ++i) {
+      double s = 0.0;
+      MAS_UNROLL for (int k = 0; k < P_; ++k) s += A[k * M_ + i] * B[j * P_ + k];
+      C[j * M_ + i] = s;
+    }
+  }
+}
+
+// Eigen::LLT (unblocked, lower) on an n x n column-major matrix; 1 if a pivot is <= 0.
+// NaN pivots pass, exactly as Eigen's `if (x <= 0) return k;`.
+template <int N>
+MAS_HD int llt_compute(double* Mx) {
+  int fail = 0;
+  MAS_UNROLL for (int k = 0; k < N; ++k) {
+    if (!fail) {
+      double x = Mx[k * N + k];
+      if (k > 0) {
+        double s = 0.0;
+        MAS_UNROLL for (int j = 0; j < k; ++j) s += Mx[j * N + k] * Mx[j * N + k];
+        x = Mx[k * N + k] - s;
+      }
+      if (x <= 0.0) {
+        fail = 1;
+      } else {
+        x = sqrt(x);
+        Mx[k * N + k] = x;
+        MAS_UNROLL for (int r = k + 1; r < N; ++r) {
+          double a = Mx[k * N + r];
+          MAS_UNROLL for (int j = 0; j < k; ++j) a += (-Mx[j * N + k]) * Mx[j * N + r];
+          Mx[k * N + r] = a / x;
+        }
+      }
+    }
+  }
+  return fail;
+}
+
+// LLT::solve(Identity) following Eigen's small triangular solver (reciprocal then multiply)
+template <int N>
+MAS_HD void llt_solve_identity(const double* Lm, double* Inv) {
+  MAS_UNROLL for (int c = 0; c < N; ++c) {
+    double o[N];
+    MAS_UNROLL for (int i = 0; i < N; ++i) o[i] = (i == c) ? 1.0 : 0.0;
+    MAS_UNROLL for (int i = 0; i < N; ++i) {
+      const double a = 1.0 / Lm[i * N + i];
+      o[i] *= a;
+      const double b = o[i];
+      MAS_UNROLL for (int r = i + 1; r < N; ++r) o[r] -= b * Lm[i * N + r];
+    }
+    MAS_UNROLL for (int i = N - 1; i >= 0; --i) {
+      const double a = 1.0 / Lm[i * N + i];
+      double b = 0.0;
+      MAS_UNROLL for (int r = i + 1; r < N; ++r) b += Lm[i * N + r] * o[r];
+      o[i] = (o[i] - b) * a;
+    }
+    MAS_UNROLL for (int i = 0; i < N; ++i) Inv[c * N + i] = o[i];
+  }
+}
+
+// Q-function of one step from its linearisation D and the value function (ilqr.hpp:115-119)
+template <class M>
+struct QFunction {
+  static constexpr int NX = M::NX, NU = M::NU;
+  double qx[NX], qu[NU], qxx[NX * NX], qux[NU * NX], quu[NU * NU];
+};
+
+template <class M>
+MAS_HD void assemble_q(const double* D, const double* vx, const double* vxx, QFunction<M>& q) {
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU;
+  double tx[NX], tu[NU], AtV[NX * NX], BtV[NU * NX], t2[NX * NX];
+  mat_AtB<NX, NX, 1>(D + L::oA, vx, tx);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) q.qx[i] = D[L::oLx + i] + tx[i];
+  mat_AtB<NX, NU, 1>(D + L::oB, vx, tu);
+  MAS_UNROLL for (int i = 0; i < NU; ++i) q.qu[i] = D[L::oLu + i] + tu[i];
+  mat_AtB<NX, NX, NX>(D + L::oA, vxx, AtV);
+  mat_AB<NX, NX, NX>(AtV, D + L::oA, t2);
+  MAS_UNROLL for (int i = 0; i < NX * NX; ++i) q.qxx[i] = D[L::oLxx + i] + t2[i];
+  mat_AtB<NX, NU, NX>(D + L::oB, vxx, BtV);
+  double t3[NU * NX];
+  mat_AB<NU, NX, NX>(BtV, D + L::oA, t3);
+  MAS_UNROLL for (int i = 0; i < NU * NX; ++i) q.qux[i] = D[L::oLux + i] + t3[i];
+  double t4[NU * NU];
+  mat_AB<NU, NX, NU>(BtV, D + L::oB, t4);
+  MAS_UNROLL for (int i = 0; i < NU * NU; ++i) q.quu[i] = D[L::oLuu + i] + t4[i];
+}
+
+// The reference's ladder is `while(true)` (ilqr.hpp:175-182) yet always ends: reg grows x10
+// per rung, overflows to +inf after ~315 rungs, and a +inf / NaN pivot is not `<= 0`.
+constexpr int kRegLadderMax = 400;
+
+// LLT with the cumulative x10 regularisation ladder.  `Lfac` receives the factor; `shift` is a
+// diagonal offset applied before the first attempt (0 for the per-agent path; the centralised
+// path passes the shared offset).  Returns rungs used.
+template <int NU>
+MAS_HD int llt_ladder(const double* quu, double* Lfac) {
+  double cur[NU * NU];
+  MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = quu[i];
+  double reg = 1e-6;
+  int rungs = 0;
+  for (;;) {
+    MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
+    if (llt_compute<NU>(Lfac) == 0) break;
+    if (rungs >= kRegLadderMax) break;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg;
+    reg *= 10.0;
+    ++rungs;
+  }
+  return rungs;
+}
+
+// gains and value update, ilqr.hpp:183-192; Lfac = factor of the REGULARISED q_uu, the value
+// update uses the UNregularised q.quu.
+template <class M>
+MAS_HD void gains_and_value(const QFunction<M>& q, const double* Lfac, double* k, double* K, double* vx, double* vxx) {
+  constexpr int NX = M::NX, NU = M::NU;
+  double inv[NU * NU], ninv[NU * NU], KtQuu[NX * NU], tx[NX], txx[NX * NX];
+  llt_solve_identity<NU>(Lfac, inv);
+  MAS_UNROLL for (int i = 0; i < NU * NU; ++i) ninv[i] = -inv[i];
+  mat_AB<NU, NU, 1>(ninv, q.qu, k);
+  mat_AB<NU, NU, NX>(ninv, q.qux, K);
+  mat_AtB<NU, NX, NU>(K, q.quu, KtQuu);
+  mat_AtB<NU, NX, 1>(K, q.qu, tx);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) vx[i] = q.qx[i] + tx[i];
+  mat_AtB<NU, NX, 1>(q.qux, k, tx);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) vx[i] = vx[i] + tx[i];
+  mat_AB<NX, NU, 1>(KtQuu, k, tx);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) vx[i] = vx[i] + tx[i];
+  mat_AtB<NU, NX, NX>(K, q.qux, txx);
+  MAS_UNROLL for (int i = 0; i < NX * NX; ++i) vxx[i] = q.qxx[i] + txx[i];
+  mat_AtB<NU, NX, NX>(q.qux, K, txx);
+  MAS_UNROLL for (int i = 0; i < NX * NX; ++i) vxx[i] = vxx[i] + txx[i];
+  mat_AB<NX, NU, NX>(KtQuu, K, txx);
+  MAS_UNROLL for (int i = 0; i < NX * NX; ++i) vxx[i] = vxx[i] + txx[i];
+  symmetrise_inplace<NX>(vxx);
+}
+
+// ------------------------------------------------------------------- forward step ------
+// one column of the line-search rollout, ilqr.hpp:210-216
+template <class M>
+MAS_HD void forward_control(const double* x_trial, const double* x_ref, const double* u_ref, const double* k, const double* K,
+                            double alpha, bool clamp, const double* lb, const double* ub, double* u_out) {
+  constexpr int NX = M::NX, NU = M::NU;
+  double dx[NX];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) dx[i] = x_trial[i] - x_ref[i];
+  MAS_UNROLL for (int i = 0; i < NU; ++i) {
+    double kd = 0.0;
+    MAS_UNROLL for (int c = 0; c < NX; ++c) kd += K[c * NU + i] * dx[c];
+    u_out[i] = (u_ref[i] + alpha * k[i]) + kd;
+  }
+  if (clamp) clamp_column<NU>(u_out, lb, ub);
+}
+
+}  // namespace mas

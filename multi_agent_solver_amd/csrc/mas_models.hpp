@@ -1,0 +1,233 @@
+// mas_models.hpp -- device-side workload models.
+//
+// The reference reaches problem-specific math through std::function callbacks on Eigen
+// vectors (include/multi_agent_solver/types.hpp:21-50), which are opaque to a GPU.  Here a
+// model is a POD parameter block plus static inline functions compiled into the kernels.
+// Which derivative is finite-differenced and which is analytic follows the reference's
+// example that defines the workload (OCP::initialize_problem installs FD defaults for every
+// hook the example leaves empty, ocp.hpp:117-135).
+//
+// All arithmetic is FP64 and is compiled with -ffp-contract=off so that every expression
+// rounds exactly like the scalar statement it restates.
+#pragma once
+
+#include <cmath>
+
+#include "mas_platform.hpp"
+
+namespace mas {
+
+struct ModelParams {
+  double p[16];
+};
+
+// ---------------------------------------------------------------------------------------
+// Single-track circular-track workload.
+//   dynamics: examples/models/single_track_model.hpp:23-44
+//   cost / bounds / constants: examples/multi_agent_single_track.cpp:46-67,103-110
+//   no analytic hooks are set by that example (:46-69) => everything FD
+// params: [0] track_radius [1] target_velocity [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L
+struct SingleTrack {
+  static constexpr int NX = 4, NU = 2;
+  static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
+                        kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
+  static constexpr bool kZeroTerminal = true;   // terminal_cost == 0 (:65): FD of it is exactly 0
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
+
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    const double psi = x[2], v = x[3], delta = u[0], a = u[1], L = P.p[6];
+    d[0] = v * cos(psi);
+    d[1] = v * sin(psi);
+    d[2] = v * tan(delta) / L;
+    d[3] = a;
+  }
+  MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
+    const double x = s[0], y = s[1], vx = s[3], delta = c[0], a_cmd = c[1];
+    const double dist = fabs(sqrt(x * x + y * y) - P.p[0]);
+    const double se = vx - P.p[1];
+    return P.p[2] * dist * dist + P.p[3] * se * se + P.p[4] * delta * delta + P.p[5] * a_cmd * a_cmd;
+  }
+  MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
+};
+
+// ---------------------------------------------------------------------------------------
+// Identity LQR: examples/multi_agent_lqr.cpp:21-76 (A=B=Q=R=Qf=I, n_x=n_u=4), every
+// derivative analytic (:35-41,46-71).
+struct LqrIdentity {
+  static constexpr int NX = 4, NU = 4;
+  static constexpr bool kAnalyticA = true, kAnalyticB = true, kAnalyticLx = true, kAnalyticLu = true,
+                        kAnalyticLxx = true, kAnalyticLuu = true, kAnalyticLux = true, kAnalyticTerm = true;
+  static constexpr bool kZeroTerminal = false;
+  static constexpr bool kDefaultBounds = false;
+  MAS_HD static void default_bounds(double*, double*) {}
+
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams&) {
+    MAS_UNROLL for (int i = 0; i < NX; ++i) d[i] = x[i] + u[i];
+  }
+  MAS_HD static double stage_cost(const double* x, const double* u, int, const ModelParams&) {
+    double a = 0.0, b = 0.0;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) a += x[i] * x[i];
+    MAS_UNROLL for (int i = 0; i < NU; ++i) b += u[i] * u[i];
+    return a + b;
+  }
+  MAS_HD static double terminal_cost(const double* x, const ModelParams&) {
+    double a = 0.0;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) a += x[i] * x[i];
+    return a;
+  }
+  MAS_HD static void A(const double*, const double*, double* M, const ModelParams&) {
+    MAS_UNROLL for (int i = 0; i < NX * NX; ++i) M[i] = 0.0;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) M[i * NX + i] = 1.0;
+  }
+  MAS_HD static void B(const double*, const double*, double* M, const ModelParams&) {
+    MAS_UNROLL for (int i = 0; i < NX * NU; ++i) M[i] = 0.0;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) M[i * NX + i] = 1.0;
+  }
+  MAS_HD static void lx(const double* x, const double*, int, double* g, const ModelParams&) { MAS_UNROLL for (int i = 0; i < NX; ++i) g[i] = 2.0 * x[i]; }
+  MAS_HD static void lu(const double*, const double* u, int, double* g, const ModelParams&) { MAS_UNROLL for (int i = 0; i < NU; ++i) g[i] = 2.0 * u[i]; }
+  MAS_HD static void lxx(const double*, const double*, int, double* H, const ModelParams&) {
+    MAS_UNROLL for (int i = 0; i < NX * NX; ++i) H[i] = 0.0;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) H[i * NX + i] = 2.0;
+  }
+  MAS_HD static void luu(const double*, const double*, int, double* H, const ModelParams&) {
+    MAS_UNROLL for (int i = 0; i < NU * NU; ++i) H[i] = 0.0;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) H[i * NU + i] = 2.0;
+  }
+  MAS_HD static void lux(const double*, const double*, int, double* H, const ModelParams&) { MAS_UNROLL for (int i = 0; i < NU * NX; ++i) H[i] = 0.0; }
+  MAS_HD static void term_grad(const double* x, double* g, const ModelParams&) { MAS_UNROLL for (int i = 0; i < NX; ++i) g[i] = 2.0 * x[i]; }
+  MAS_HD static void term_hess(const double*, double* H, const ModelParams&) {
+    MAS_UNROLL for (int i = 0; i < NX * NX; ++i) H[i] = 0.0;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) H[i * NX + i] = 2.0;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Pendulum swing-up: examples/models/pendulum_model.hpp:8-20, examples/pendulum_swing_up.cpp:29-117.
+// No analytic hooks are wired by the example => FD.  params: [0] horizon_d (the T in s = k/(T-1)).
+struct Pendulum {
+  static constexpr int NX = 2, NU = 1;
+  static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
+                        kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
+  static constexpr bool kZeroTerminal = false;
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -5.0; ub[0] = 5.0; }
+
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams&) {
+    const double g = 9.81, l = 1.0, m = 1.0, b = 0.1;
+    d[0] = x[1];
+    d[1] = (g / l) * sin(x[0]) + u[0] / (m * l * l) - (b / (m * l * l)) * x[1];
+  }
+  MAS_HD static double stage_cost(const double* x, const double* u, int k, const ModelParams& P) {
+    const double g = 9.81, l = 1.0, m = 1.0, mgl = m * g * l, E_des = mgl;
+    const double w_energy = 2.0, w_u = 0.05, w_shape = 2.0, w_omega = 0.05;
+    const double horizon_d = P.p[0];
+    const double theta = x[0], omega = x[1], torque = u[0];
+    const double s = static_cast<double>(k) / (horizon_d - 1.0);
+    const double late = s * s, early = 1.0 - late;
+    const double w_energy_k = w_energy * (0.2 + 0.8 * early);
+    const double w_shape_k = w_shape * (0.2 + 0.8 * late);
+    const double w_omega_k = w_omega * (0.2 + 0.8 * late);
+    const double Tk = 0.5 * m * l * l * omega * omega;
+    const double V = mgl * cos(theta);
+    const double E = Tk + V;
+    const double energy_error = (E - E_des) / mgl;
+    const double upright_error = 1.0 - cos(theta);
+    return w_energy_k * energy_error * energy_error + w_shape_k * upright_error + w_omega_k * omega * omega + w_u * torque * torque;
+  }
+  MAS_HD static double terminal_cost(const double* x, const ModelParams&) {
+    const double wT_pos = 500.0, wT_vel = 100.0;
+    const double upright_error = 1.0 - cos(x[0]);
+    return wT_pos * upright_error + wT_vel * x[1] * x[1];
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Single-track lane following: examples/single_track_ocp.cpp:14-116.  Analytic A,B
+// (models/single_track_model.hpp:49-82) and l_x,l_u,l_xx,l_uu (:62-94); the cross term and
+// the (zero) terminal derivatives stay FD.
+// params: [0] desired_velocity [1] w_lane [2] w_speed [3] w_delta [4] w_acc [6] L
+struct SingleTrackLane {
+  static constexpr int NX = 4, NU = 2;
+  static constexpr bool kAnalyticA = true, kAnalyticB = true, kAnalyticLx = true, kAnalyticLu = true,
+                        kAnalyticLxx = true, kAnalyticLuu = true, kAnalyticLux = false, kAnalyticTerm = false;
+  static constexpr bool kZeroTerminal = true;
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -0.7; lb[1] = -1.0; ub[0] = 0.7; ub[1] = 1.0; }
+
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) { SingleTrack::dynamics(x, u, d, P); }
+  MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
+    const double y = s[1], vx = s[3], delta = c[0], a_cmd = c[1];
+    const double lane_error = y, speed_error = vx - P.p[0];
+    return P.p[1] * (lane_error * lane_error) + P.p[2] * (speed_error * speed_error) + P.p[3] * (delta * delta) + P.p[4] * (a_cmd * a_cmd);
+  }
+  MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
+  MAS_HD static void A(const double* x, const double* u, double* M, const ModelParams& P) {
+    const double psi = x[2], v = x[3], delta = u[0], L = P.p[6];
+    MAS_UNROLL for (int i = 0; i < 16; ++i) M[i] = 0.0;
+    M[2 * 4 + 0] = -v * sin(psi); M[3 * 4 + 0] = cos(psi);
+    M[2 * 4 + 1] = v * cos(psi);  M[3 * 4 + 1] = sin(psi);
+    M[3 * 4 + 2] = tan(delta) / L;
+  }
+  MAS_HD static void B(const double* x, const double* u, double* M, const ModelParams& P) {
+    const double v = x[3], delta = u[0], L = P.p[6];
+    MAS_UNROLL for (int i = 0; i < 8; ++i) M[i] = 0.0;
+    M[0 * 4 + 2] = v / (L * cos(delta) * cos(delta));
+    M[1 * 4 + 3] = 1.0;
+  }
+  MAS_HD static void lx(const double* x, const double*, int, double* g, const ModelParams& P) { g[0] = 0.0; g[1] = 2.0 * P.p[1] * x[1]; g[2] = 0.0; g[3] = 2.0 * P.p[2] * (x[3] - P.p[0]); }
+  MAS_HD static void lu(const double*, const double* u, int, double* g, const ModelParams& P) { g[0] = 2.0 * P.p[3] * u[0]; g[1] = 2.0 * P.p[4] * u[1]; }
+  MAS_HD static void lxx(const double*, const double*, int, double* H, const ModelParams& P) {
+    MAS_UNROLL for (int i = 0; i < 16; ++i) H[i] = 0.0;
+    H[1 * 4 + 1] = 2.0 * P.p[1]; H[3 * 4 + 3] = 2.0 * P.p[2];
+  }
+  MAS_HD static void luu(const double*, const double*, int, double* H, const ModelParams& P) { H[0] = 2.0 * P.p[3]; H[1] = 0.0; H[2] = 0.0; H[3] = 2.0 * P.p[4]; }
+};
+
+// ---------------------------------------------------------------------------------------
+// bicycle6: THIS REPOSITORY'S OWN 6-state model for BASELINE config 5 (the reference has no
+// nx=6 model).  Kinematic bicycle with steering angle and acceleration as
+// states and their rates as controls; circular-track cost as in the single-track example.
+//   state [X, Y, psi, v, delta, a], control [delta_rate, jerk]
+// params: [0] R [1] vt [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L [7] w_rate
+struct Bicycle6 {
+  static constexpr int NX = 6, NU = 2;
+  static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
+                        kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
+  static constexpr bool kZeroTerminal = true;
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
+
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    const double psi = x[2], v = x[3], delta = x[4], a = x[5], L = P.p[6];
+    d[0] = v * cos(psi); d[1] = v * sin(psi); d[2] = v * tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
+  }
+  MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
+    const double x = s[0], y = s[1], vx = s[3], delta = s[4], a = s[5];
+    const double dist = fabs(sqrt(x * x + y * y) - P.p[0]);
+    const double se = vx - P.p[1];
+    return P.p[2] * dist * dist + P.p[3] * se * se + P.p[4] * delta * delta + P.p[5] * a * a + P.p[7] * c[0] * c[0] + P.p[7] * c[1] * c[1];
+  }
+  MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
+};
+
+// number of doubles the linearisation of one (agent, t) produces: A,B,l_x,l_u,l_xx,l_uu,l_ux
+template <class M>
+struct DerivLayout {
+  static constexpr int NX = M::NX, NU = M::NU;
+  static constexpr int oA = 0, oB = oA + NX * NX, oLx = oB + NX * NU, oLu = oLx + NX, oLxx = oLu + NU,
+                       oLuu = oLxx + NX * NX, oLux = oLuu + NU * NU, ND = oLux + NU * NX;
+};
+
+inline void model_default_params(int model_id, int T, double* p) {
+  for (int i = 0; i < 16; ++i) p[i] = 0.0;
+  switch (model_id) {
+    case 1: p[0] = 20.0; p[1] = 5.0; p[2] = 1.0; p[3] = 1.0; p[4] = 0.001; p[5] = 0.001; p[6] = 2.5; break;  // multi_agent_single_track.cpp:49-52,109-110
+    case 3: p[0] = static_cast<double>(T); break;                                                       // pendulum_swing_up.cpp:62
+    case 4: p[0] = 1.0; p[1] = 10.0; p[2] = 1.0; p[3] = 0.1; p[4] = 0.1; p[6] = 2.5; break;              // single_track_ocp.cpp:34-40
+    case 5: p[0] = 20.0; p[1] = 5.0; p[2] = 1.0; p[3] = 1.0; p[4] = 0.001; p[5] = 0.001; p[6] = 2.5; p[7] = 0.001; break;
+    default: break;
+  }
+}
+
+}  // namespace mas

@@ -1,0 +1,386 @@
+// mas_solver.hpp -- host-side batch driver of the MI355X iLQR path.
+//
+// One BatchSolver owns the device-resident state of N independent agents of one workload
+// model and runs the reference's strategies over them:
+//   solve()            N x iLQR::solve                         ilqr.hpp:58-273 / nash.hpp:59-64
+//   run_sequential()   detail::run_sequential                  nash.hpp:74-90
+//   run_trust_region() detail::run_trust_region                nash.hpp:182-248
+//   run_line_search()  detail::run_line_search                 nash.hpp:92-180
+//   run_centralized()  CentralizedStrategy (block-diagonal)    centralized.hpp:18-38
+// Per batch iteration it launches: linearisation sweep -> backward Riccati -> speculative
+// line search -> select -> commit, and reads back one integer (agents still active).
+#pragma once
+
+#include <cmath>
+#include <limits>
+#include <memory>
+
+#include "mas_backend.hpp"
+#include "mas_bodies.hpp"
+#include "mas_central.hpp"
+
+namespace mas {
+
+struct ProblemDesc {
+  int model_id = 0, n_agents = 0, horizon_steps = 0, device = 0;
+  double dt = 0.0;
+  bool has_params = false; double params[16] = {0};
+  bool has_bounds = false, no_bounds = false; double lb[8] = {0}, ub[8] = {0};
+};
+
+struct HostStats {
+  int64_t agent_iterations = 0, converged_solves = 0, solves = 0, reg_events = 0, batch_iterations = 0;
+  double wall_ms = 0.0;
+};
+
+class SolverBase {
+ public:
+  virtual ~SolverBase() = default;
+  virtual int nx() const = 0;
+  virtual int nu() const = 0;
+  virtual void set_initial_states(const double* x0, bool device_ptr) = 0;
+  virtual void set_controls(const double* U, bool device_ptr) = 0;
+  virtual void initialize_problem() = 0;
+  virtual void save_initial() = 0;
+  virtual void restore_initial() = 0;
+  virtual void solve() = 0;
+  virtual void run_sequential(int max_outer) = 0;
+  virtual void run_trust_region(int max_outer) = 0;
+  virtual void run_line_search(int max_outer) = 0;
+  virtual void run_centralized() = 0;
+  virtual void get_solution(double* X, double* U, double* cost, int32_t* iters, int32_t* exit_code, bool device_ptr) = 0;
+  virtual double total_cost() = 0;
+  virtual void get_trust_radii(double* radii) = 0;
+  virtual void debug_backward(double* derivs, double* k, double* K, int64_t* regs) = 0;
+  virtual HostStats get_stats() = 0;
+  virtual void reset_stats() = 0;
+
+  // iLQR::set_params, ilqr.hpp:39-55
+  bool set_param(const std::string& key, double value) {
+    if (key == "max_iterations") { max_iterations = static_cast<int>(value); has_max_iterations = true; }
+    else if (key == "tolerance") { tolerance = value; has_tolerance = true; }
+    else if (key == "max_ms") { max_ms = value; has_max_ms = true; }
+    else if (key == "debug") { debug = value > 0.5; }
+    else return false;   // penalty*, constraint_tolerance, ... and unknown keys: ignored
+    return true;
+  }
+  bool params_complete() const { return has_max_iterations && has_tolerance && has_max_ms; }
+
+  Backend be;
+  std::string last_error;
+  // defaults of the iLQR constructor, ilqr.hpp:26-37
+  int max_iterations = 50;
+  double tolerance = 1e-6;
+  double max_ms = std::numeric_limits<double>::infinity();
+  bool debug = false;
+  bool has_max_iterations = false, has_tolerance = false, has_max_ms = false;
+};
+
+template <class M>
+class SolverImpl final : public SolverBase {
+  static constexpr int NX = M::NX, NU = M::NU;
+  using L = DerivLayout<M>;
+
+ public:
+  SolverImpl(const ProblemDesc& desc, void* external_stream) {
+    d.N = desc.n_agents; d.T = desc.horizon_steps; d.Np = (static_cast<size_t>(desc.n_agents) + 63) / 64 * 64;
+    dt = desc.dt;
+    if (desc.has_params) for (int i = 0; i < 16; ++i) P.p[i] = desc.params[i];
+    else model_default_params(desc.model_id, desc.horizon_steps, P.p);
+    clamp = false;
+    for (int i = 0; i < NU; ++i) { lb[i] = 0.0; ub[i] = 0.0; }
+    if (!desc.no_bounds) {
+      if (desc.has_bounds) { for (int i = 0; i < NU; ++i) { lb[i] = desc.lb[i]; ub[i] = desc.ub[i]; } clamp = true; }
+      else if (M::kDefaultBounds) { M::default_bounds(lb, ub); clamp = true; }
+    }
+    be.init(desc.device, external_stream);
+    const size_t Np = d.Np; const int T = d.T;
+    x0 = dalloc(NX * Np); X = dalloc((T + 1) * NX * Np); U = dalloc(static_cast<size_t>(T) * NU * Np);
+    D = dalloc(static_cast<size_t>(T) * L::ND * Np);
+    kff = dalloc(static_cast<size_t>(T) * NU * Np); Kfb = dalloc(static_cast<size_t>(T) * NU * NX * Np);
+    Xs = dalloc(static_cast<size_t>(kNumAlphas) * (T + 1) * NX * Np); Us = dalloc(static_cast<size_t>(kNumAlphas) * T * NU * Np);
+    trial_merit = dalloc(static_cast<size_t>(kNumAlphas) * Np);
+    cost = dalloc(Np); merit = dalloc(Np);
+    x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
+    active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
+    reg_events = static_cast<long long*>(be.alloc(sizeof(long long) * Np));
+    counters = static_cast<long long*>(be.alloc(sizeof(long long) * 8));
+    central = static_cast<CentralState*>(be.alloc(sizeof(CentralState)));
+    const size_t stage_elems = static_cast<size_t>(d.N) * std::max<size_t>(static_cast<size_t>(T + 1) * NX, static_cast<size_t>(T) * std::max(L::ND, NU * NX));
+    stage = dalloc(stage_elems);
+    host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 8));
+    host_central = static_cast<CentralState*>(be.alloc_pinned(sizeof(CentralState)));
+    be.sync();
+  }
+  ~SolverImpl() override {
+    for (void* p : allocations) be.free(p);
+    be.free_pinned(host_counters); be.free_pinned(host_central);
+    be.destroy();
+  }
+
+  int nx() const override { return NX; }
+  int nu() const override { return NU; }
+
+  void set_initial_states(const double* src, bool device_ptr) override {
+    upload(src, static_cast<size_t>(d.N) * NX, device_ptr);
+    be.template launch_2d<1>("aos_to_soa", AosToSoaBody{d, NX, stage, x0, 1}, d.N, 1);
+    have_x0 = true; initialized = false;
+  }
+  void set_controls(const double* src, bool device_ptr) override {
+    if (!src) { be.zero(U, sizeof(double) * d.T * NU * d.Np); }
+    else {
+      upload(src, static_cast<size_t>(d.N) * d.T * NU, device_ptr);
+      be.template launch_2d<4>("aos_to_soa", AosToSoaBody{d, NU, stage, U, d.T}, d.N, d.T);
+    }
+    initialized = false;
+  }
+  void initialize_problem() override {
+    require(have_x0, "initial states not set");
+    be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
+    if (!radii) radii = dalloc(d.Np);
+    initialized = true;
+  }
+  void save_initial() override {
+    be.d2d(x0_saved, x0, sizeof(double) * NX * d.Np); be.d2d(U_saved, U, sizeof(double) * d.T * NU * d.Np); saved = true;
+  }
+  void restore_initial() override {
+    require(saved, "no saved initial state");
+    be.d2d(x0, x0_saved, sizeof(double) * NX * d.Np); be.d2d(U, U_saved, sizeof(double) * d.T * NU * d.Np);
+    be.zero(iters_total, sizeof(int) * d.Np); be.zero(reg_events, sizeof(long long) * d.Np);
+    have_x0 = true;
+    initialize_problem();
+  }
+
+  // ---------------------------------------------------------------- N x iLQR::solve ------
+  void solve() override { Timer tm(*this); solve_all(); }
+
+  void run_sequential(int max_outer) override {          // nash.hpp:74-90
+    Timer tm(*this);
+    ensure_initialized();
+    for (int outer = 0; outer < max_outer; ++outer) solve_all();   // update_initial_with_best (nash.hpp:66-71) has no device-side effect
+    last_total_valid = false;
+  }
+
+  void run_trust_region(int max_outer) override {        // nash.hpp:182-248
+    Timer tm(*this);
+    ensure_initialized();
+    ensure_snapshots();
+    fill(radii, 1.0);
+    for (int outer = 0; outer < max_outer; ++outer) {
+      be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
+      be.d2d(cost_old, cost, sizeof(double) * d.Np);
+      solve_all();
+      be.template launch_1d<1>("trust_region", TrustRegionBody<M>{d, dt, P, x0, X, U, cost, X_old, U_old, cost_old, radii}, d.N);
+    }
+    last_total_valid = false;
+  }
+
+  void run_line_search(int max_outer) override {         // nash.hpp:92-180
+    Timer tm(*this);
+    ensure_initialized();
+    ensure_snapshots();
+    double base_cost = host_sum(cost);
+    for (int outer = 0; outer < max_outer; ++outer) {
+      be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
+      be.d2d(cost_old, cost, sizeof(double) * d.Np);
+      solve_all();
+      const double new_cost = host_sum(cost);
+      if (new_cost >= base_cost) {
+        be.d2d(U_cand, U, sizeof(double) * d.T * NU * d.Np);
+        double alpha = 0.5; bool accepted = false;
+        while (alpha > 1e-3 && !accepted) {
+          be.template launch_1d<1>("blend_rollout", BlendRolloutBody<M>{d, dt, alpha, P, x0, U_old, U_cand, X, U, cost}, d.N);
+          const double trial_cost = host_sum(cost);
+          if (trial_cost < base_cost) { base_cost = trial_cost; accepted = true; }
+          else alpha *= 0.5;
+        }
+        if (!accepted) {
+          be.d2d(X, X_old, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U, U_old, sizeof(double) * d.T * NU * d.Np);
+          be.d2d(cost, cost_old, sizeof(double) * d.Np);   // objective(old) == the stored old cost
+        }
+      } else base_cost = new_cost;
+    }
+    last_total_valid = false;
+  }
+
+  void run_centralized() override {                      // centralized.hpp:18-38, block-diagonal reading
+    Timer tm(*this);
+    require(have_x0, "initial states not set");
+    require(d.N <= kCentralMaxAgents, "centralized strategy supports at most 1024 agents per device");
+    be.zero(U, sizeof(double) * d.T * NU * d.Np);       // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109)
+    initialize_problem();
+    be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
+    be.launch_group("central_init", CentralInitBody{d, cost, central}, d.N);
+    stats.solves += 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    int exit_reason = kExitMaxIter;
+    for (int iter = 0; iter < max_iterations; ++iter) {
+      if (timed_out(t0)) { exit_reason = kExitTime; break; }
+      const double nact = static_cast<double>(d.N);
+      be.template launch_2d<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, d.N, d.T, sweep_bytes() * nact);
+      be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events}, d.N, backward_bytes() * nact);
+      be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
+      be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
+      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      be.d2h(host_central, central, sizeof(CentralState));
+      stats.batch_iterations++;
+      if (host_central->done) { exit_reason = kExitConverged; break; }
+    }
+    be.d2h(host_central, central, sizeof(CentralState));
+    central_total = host_central->cur_total; last_total_valid = true;
+    if (exit_reason == kExitConverged) stats.converged_solves += 1;
+    fill_int(exit_code, exit_reason);
+  }
+
+  void get_solution(double* Xo, double* Uo, double* co, int32_t* it, int32_t* ex, bool device_ptr) override {
+    if (Xo) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NX, X, stage, d.T + 1}, d.N, d.T + 1); download(Xo, static_cast<size_t>(d.N) * (d.T + 1) * NX, device_ptr); }
+    if (Uo) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, U, stage, d.T}, d.N, d.T); download(Uo, static_cast<size_t>(d.N) * d.T * NU, device_ptr); }
+    if (co) { if (device_ptr) be.d2d(co, cost, sizeof(double) * d.N); else be.d2h(co, cost, sizeof(double) * d.N); }
+    if (it) be.d2h(it, iters_total, sizeof(int) * d.N);
+    if (ex) be.d2h(ex, exit_code, sizeof(int) * d.N);
+    be.sync();
+  }
+  double total_cost() override { return last_total_valid ? central_total : host_sum(cost); }
+  void get_trust_radii(double* out) override { require(radii != nullptr, "no trust radii"); be.d2h(out, radii, sizeof(double) * d.N); }
+
+  void debug_backward(double* derivs, double* ko, double* Ko, int64_t* regs) override {
+    ensure_initialized();
+    be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
+    be.zero(reg_events, sizeof(long long) * d.Np);
+    be.template launch_2d<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, d.N, d.T);
+    be.template launch_1d<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, d.N);
+    if (derivs) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, L::ND, D, stage, d.T}, d.N, d.T); download(derivs, static_cast<size_t>(d.N) * d.T * L::ND, false); }
+    if (ko) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, kff, stage, d.T}, d.N, d.T); download(ko, static_cast<size_t>(d.N) * d.T * NU, false); }
+    if (Ko) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU * NX, Kfb, stage, d.T}, d.N, d.T); download(Ko, static_cast<size_t>(d.N) * d.T * NU * NX, false); }
+    if (regs) { std::vector<long long> h(d.N); be.d2h(h.data(), reg_events, sizeof(long long) * d.N); int64_t s = 0; for (auto v : h) s += v; *regs = s; }
+    be.zero(reg_events, sizeof(long long) * d.Np);
+  }
+
+  HostStats get_stats() override {
+    std::vector<int> it(d.N); std::vector<long long> rg(d.N);
+    be.d2h(it.data(), iters_total, sizeof(int) * d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N);
+    HostStats s = stats; s.agent_iterations = 0; s.reg_events = 0;
+    for (int v : it) s.agent_iterations += v;
+    for (auto v : rg) s.reg_events += v;
+    return s;
+  }
+  void reset_stats() override {
+    stats = HostStats{};
+    be.zero(iters_total, sizeof(int) * d.Np); be.zero(reg_events, sizeof(long long) * d.Np);
+  }
+
+ private:
+  struct Timer {
+    SolverImpl& s; std::chrono::steady_clock::time_point t0;
+    explicit Timer(SolverImpl& s_) : s(s_), t0(std::chrono::steady_clock::now()) {}
+    ~Timer() {
+      try { s.be.sync(); } catch (...) {}
+      s.stats.wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  };
+
+  void require(bool ok, const char* what) const { if (!ok) throw std::logic_error(what); }
+  void ensure_initialized() { if (!initialized) initialize_problem(); }
+  void ensure_snapshots() {
+    if (X_old) return;
+    X_old = dalloc((d.T + 1) * NX * d.Np); U_old = dalloc(static_cast<size_t>(d.T) * NU * d.Np); cost_old = dalloc(d.Np);
+    U_cand = dalloc(static_cast<size_t>(d.T) * NU * d.Np);
+  }
+  bool timed_out(std::chrono::steady_clock::time_point t0) const {
+    // ilqr.hpp:84-90: elapsed truncated to whole milliseconds, compared with max_ms.  All solves of a
+    // batch start together, so one host clock stands for every agent's.
+    if (std::isinf(max_ms) && max_ms > 0) return false;
+    const double elapsed_ms = static_cast<double>(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count());
+    return elapsed_ms > max_ms;
+  }
+
+  // algorithmic bytes per agent and launch
+  double sweep_bytes() const { return 8.0 * ((NX + NU) * d.T) + 8.0 * d.T * L::ND; }
+  double backward_bytes() const { return 8.0 * d.T * L::ND + 8.0 * NX + 8.0 * d.T * (NU + NU * NX); }
+  double forward_bytes() const { return 8.0 * (d.T * (NX + NU + NU + NU * NX) + NX) + 8.0 * ((d.T + 1) * NX + d.T * NU); }
+
+  ForwardBody<M> make_forward() const {
+    ForwardBody<M> f;
+    f.d = d; f.dt = dt; f.P = P; f.clamp = clamp;
+    for (int i = 0; i < NU; ++i) { f.lb[i] = lb[i]; f.ub[i] = ub[i]; }
+    f.x0 = x0; f.X = X; f.U = U; f.kff = kff; f.Kfb = Kfb; f.Xs = Xs; f.Us = Us; f.trial_merit = trial_merit; f.active = active;
+    return f;
+  }
+
+  // N x iLQR::solve with per-agent acceptance and termination
+  void solve_all() {
+    ensure_initialized();
+    be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
+    // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78)
+    be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
+    stats.solves += d.N;
+    const auto t0 = std::chrono::steady_clock::now();
+    long long n_active = d.N;
+    for (int iter = 0; iter < max_iterations && n_active > 0; ++iter) {
+      if (timed_out(t0)) { be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N); break; }
+      const double nact = static_cast<double>(n_active);
+      be.template launch_2d<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, d.N, d.T, sweep_bytes() * nact);
+      be.template launch_1d<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, d.N, backward_bytes() * nact);
+      be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
+      be.zero(counters, sizeof(long long) * 2);
+      be.template launch_1d<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
+                                                    iters_total, exit_code, reinterpret_cast<int*>(counters), counters + 1}, d.N);
+      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      be.d2h(host_counters, counters, sizeof(long long) * 2);
+      n_active = static_cast<long long>(reinterpret_cast<int*>(host_counters)[0]);
+      stats.converged_solves += host_counters[1];
+      stats.batch_iterations++;
+    }
+  }
+
+  double host_sum(const double* dev) {      // Solution.total_cost: serial sum in block order (nash.hpp:23-37)
+    std::vector<double> h(d.N); be.d2h(h.data(), dev, sizeof(double) * d.N);
+    double c = 0.0; for (double v : h) c += v; return c;
+  }
+  void fill(double* dev, double v) { std::vector<double> h(d.Np, v); be.h2d(dev, h.data(), sizeof(double) * d.Np); }
+  void fill_int(int* dev, int v) { std::vector<int> h(d.Np, v); be.h2d(dev, h.data(), sizeof(int) * d.Np); }
+  void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); } else be.h2d(stage, src, sizeof(double) * n); }
+  void download(double* dst, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(dst, stage, sizeof(double) * n); be.sync(); } else be.d2h(dst, stage, sizeof(double) * n); }
+  double* dalloc(size_t n) { void* p = be.alloc(sizeof(double) * n); allocations.push_back(p); return static_cast<double*>(p); }
+  int* ialloc(size_t n) { void* p = be.alloc(sizeof(int) * n); allocations.push_back(p); return static_cast<int*>(p); }
+
+  Dims d{}; double dt = 0.0; ModelParams P{}; bool clamp = false; double lb[NU], ub[NU];
+  double *x0 = nullptr, *X = nullptr, *U = nullptr, *D = nullptr, *kff = nullptr, *Kfb = nullptr, *Xs = nullptr, *Us = nullptr;
+  double *trial_merit = nullptr, *cost = nullptr, *merit = nullptr, *x0_saved = nullptr, *U_saved = nullptr, *stage = nullptr;
+  double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
+  int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
+  long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
+  CentralState *central = nullptr, *host_central = nullptr;
+  std::vector<void*> allocations;
+  bool have_x0 = false, initialized = false, saved = false, last_total_valid = false;
+  double central_total = 0.0;
+  HostStats stats;
+};
+
+inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* external_stream) {
+  switch (desc.model_id) {
+    case 1: return std::make_unique<SolverImpl<SingleTrack>>(desc, external_stream);
+    case 2: return std::make_unique<SolverImpl<LqrIdentity>>(desc, external_stream);
+    case 3: return std::make_unique<SolverImpl<Pendulum>>(desc, external_stream);
+    case 4: return std::make_unique<SolverImpl<SingleTrackLane>>(desc, external_stream);
+    case 5: return std::make_unique<SolverImpl<Bicycle6>>(desc, external_stream);
+    default: return nullptr;
+  }
+}
+
+inline bool model_dims(int model_id, int* nx, int* nu) {
+  int a = 0, b = 0;
+  switch (model_id) {
+    case 1: a = SingleTrack::NX; b = SingleTrack::NU; break;
+    case 2: a = LqrIdentity::NX; b = LqrIdentity::NU; break;
+    case 3: a = Pendulum::NX; b = Pendulum::NU; break;
+    case 4: a = SingleTrackLane::NX; b = SingleTrackLane::NU; break;
+    case 5: a = Bicycle6::NX; b = Bicycle6::NU; break;
+    default: return false;
+  }
+  if (nx) *nx = a;
+  if (nu) *nu = b;
+  return true;
+}
+
+}  // namespace mas
