@@ -1,0 +1,122 @@
+/*
+ * mas_dettrig.h -- portable, bit-reproducible sin / cos / tan for FP64.
+ *
+ * WHY.  The reference's iLQR is numerically chaotic on its own benchmark workload: a 1-ulp
+ * change of one input moves converged single-track costs by 3 % .. 170 % at H=100
+ * (tests/test_oracle_sensitivity.py reproduces this on the CPU oracle alone), because the
+ * second-difference Hessians amplify rounding noise by 1/eps^2 = 1e10 and the x10
+ * regularisation ladder is a discontinuous function of its input.  glibc and ROCm's ocml
+ * disagree in the last bit of sin/cos/tan now and then, so no GPU implementation can agree
+ * with a glibc-linked CPU run to any useful tolerance -- unless both sides evaluate the
+ * transcendental functions with the SAME sequence of IEEE-754 operations.  This header is
+ * that sequence: only + - * / , rint and integer masks, no fma, no tables, no libm.  Compiled
+ * with -ffp-contract=off it returns identical bits under gcc on x86-64 and hipcc on gfx950.
+ *
+ * WHAT.  Three-stage Cody-Waite reduction by pi/2 (33-bit pieces, exact products for
+ * |n| < 2^20, i.e. |x| < 1.6e6), then degree-17 / degree-16 Taylor polynomials on
+ * [-pi/4, pi/4] with a first-order correction for the reduction tail; tan = sin / cos.
+ * Accuracy against glibc (tests/test_dettrig.py): sin, cos <= 1 ulp, tan <= 3 ulp.
+ * Outside the reduction range, and for NaN/Inf, the platform libm is used (not reproducible;
+ * no workload in this repository gets there).
+ *
+ * Both the product (multi_agent_solver_amd/csrc) and the CPU oracle (oracle/, in its
+ * "det" trig mode) include this file, exactly as both would link one libm.
+ * Constants: tools/gen_dettrig_constants.py (exact rational / 120-digit decimal arithmetic).
+ */
+#ifndef MAS_DETTRIG_H
+#define MAS_DETTRIG_H
+
+#include <math.h>
+
+#ifndef MAS_DT_FN
+#if defined(__HIPCC__)
+#define MAS_DT_FN static __host__ __device__ __forceinline__
+#else
+#define MAS_DT_FN static inline
+#endif
+#endif
+
+#define MAS_DT_MAX_ARG 1.6e6
+
+/* reduce x to y0 + y1 in [-pi/4, pi/4] (y1 = tail), return the quadrant n mod 4 */
+MAS_DT_FN int mas_dt_rem_pio2(double x, double* y0, double* y1) {
+  const double invpio2 = 0x1.45f306dc9c883p-1;
+  const double pio2_1 = 0x1.921fb54400000p+0, pio2_1t = 0x1.0b4611a626331p-34;
+  const double pio2_2 = 0x1.0b4611a600000p-34, pio2_2t = 0x1.3198a2e037073p-69;
+  const double pio2_3 = 0x1.3198a2e000000p-69, pio2_3t = 0x1.b839a252049c1p-104;
+  const double fn = rint(x * invpio2);
+  double r = x - fn * pio2_1;
+  double w = fn * pio2_1t;
+  double t = r;
+  w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
+  t = r;
+  w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
+  *y0 = r - w;
+  *y1 = (r - *y0) - w;
+  return ((int)fn) & 3;
+}
+
+/* sin(x + y) for |x| <= pi/4, |y| << |x| */
+MAS_DT_FN double mas_dt_ksin(double x, double y) {
+  const double S3 = -0x1.5555555555555p-3, S5 = 0x1.1111111111111p-7, S7 = -0x1.a01a01a01a01ap-13,
+               S9 = 0x1.71de3a556c734p-19, S11 = -0x1.ae64567f544e4p-26, S13 = 0x1.6124613a86d09p-33,
+               S15 = -0x1.ae7f3e733b81fp-41, S17 = 0x1.952c77030ad4ap-49;
+  const double z = x * x;
+  double p = S17;
+  p = p * z + S15; p = p * z + S13; p = p * z + S11; p = p * z + S9; p = p * z + S7; p = p * z + S5;
+  const double v = z * x;
+  /* x + (v*(S3 + z*p) + y*(1 - z/2)) */
+  return x + (v * (S3 + z * p) + y * (1.0 - 0.5 * z));
+}
+
+/* cos(x + y) for |x| <= pi/4 */
+MAS_DT_FN double mas_dt_kcos(double x, double y) {
+  const double C4 = 0x1.5555555555555p-5, C6 = -0x1.6c16c16c16c17p-10, C8 = 0x1.a01a01a01a01ap-16,
+               C10 = -0x1.27e4fb7789f5cp-22, C12 = 0x1.1eed8eff8d898p-29, C14 = -0x1.93974a8c07c9dp-37,
+               C16 = 0x1.ae7f3e733b81fp-45;
+  const double z = x * x;
+  double q = C16;
+  q = q * z + C14; q = q * z + C12; q = q * z + C10; q = q * z + C8; q = q * z + C6; q = q * z + C4;
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + ((z * z) * q - x * y));
+}
+
+MAS_DT_FN int mas_dt_in_range(double x) { return fabs(x) <= MAS_DT_MAX_ARG; } /* false for NaN */
+
+MAS_DT_FN double mas_dt_sin(double x) {
+  if (!mas_dt_in_range(x)) return sin(x);
+  double y0, y1;
+  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const double r = (n & 1) ? mas_dt_kcos(y0, y1) : mas_dt_ksin(y0, y1);
+  return (n & 2) ? -r : r;
+}
+
+MAS_DT_FN double mas_dt_cos(double x) {
+  if (!mas_dt_in_range(x)) return cos(x);
+  double y0, y1;
+  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const double r = (n & 1) ? mas_dt_ksin(y0, y1) : mas_dt_kcos(y0, y1);
+  return ((n + 1) & 2) ? -r : r;
+}
+
+/* both at once (one reduction); bitwise equal to mas_dt_sin / mas_dt_cos */
+MAS_DT_FN void mas_dt_sincos(double x, double* sn, double* cs) {
+  if (!mas_dt_in_range(x)) { *sn = sin(x); *cs = cos(x); return; }
+  double y0, y1;
+  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const double s = mas_dt_ksin(y0, y1), c = mas_dt_kcos(y0, y1);
+  const double rs = (n & 1) ? c : s, rc = (n & 1) ? s : c;
+  *sn = (n & 2) ? -rs : rs;
+  *cs = ((n + 1) & 2) ? -rc : rc;
+}
+
+MAS_DT_FN double mas_dt_tan(double x) {
+  if (!mas_dt_in_range(x)) return tan(x);
+  double y0, y1;
+  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const double s = mas_dt_ksin(y0, y1), c = mas_dt_kcos(y0, y1);
+  return (n & 1) ? -(c / s) : s / c;
+}
+
+#endif /* MAS_DETTRIG_H */

@@ -55,10 +55,28 @@ class MasHipError(RuntimeError):
         self.code = code
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes
+    in one process cannot both initialise the GPU, so when torch is installed its copy is loaded first
+    (RTLD_GLOBAL, without importing torch) and libmas_hip.so then binds to it by SONAME."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load(path: str = LIB_PATH) -> C.CDLL:
     if not os.path.exists(path):
         raise ImportError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); multi_agent_solver_amd has no CPU fallback")
+    if os.path.basename(path) == "libmas_hip.so":
+        _preload_torch_hip_runtime()
     lib = C.CDLL(path)
     d, vp, i32 = C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int32)
     lib.mas_hip_last_error.restype = C.c_char_p

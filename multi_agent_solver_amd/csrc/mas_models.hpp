@@ -8,12 +8,16 @@
 // hook the example leaves empty, ocp.hpp:117-135).
 //
 // All arithmetic is FP64 and is compiled with -ffp-contract=off so that every expression
-// rounds exactly like the scalar statement it restates.
+// rounds exactly like the scalar statement it restates.  sin/cos/tan come from
+// include/mas_dettrig.h (pure IEEE + - * /), NOT from ocml: the algorithm is chaotic under
+// last-bit differences (see that header), so the transcendental functions must be the same
+// instruction sequence on the GPU and in the CPU oracle.
 #pragma once
 
 #include <cmath>
 
 #include "mas_platform.hpp"
+#include "../../include/mas_dettrig.h"   // bit-reproducible sin/cos/tan shared with the oracle's "det" mode
 
 namespace mas {
 
@@ -37,9 +41,9 @@ struct SingleTrack {
 
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
     const double psi = x[2], v = x[3], delta = u[0], a = u[1], L = P.p[6];
-    d[0] = v * cos(psi);
-    d[1] = v * sin(psi);
-    d[2] = v * tan(delta) / L;
+    d[0] = v * mas_dt_cos(psi);
+    d[1] = v * mas_dt_sin(psi);
+    d[2] = v * mas_dt_tan(delta) / L;
     d[3] = a;
   }
   MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
@@ -116,7 +120,7 @@ struct Pendulum {
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams&) {
     const double g = 9.81, l = 1.0, m = 1.0, b = 0.1;
     d[0] = x[1];
-    d[1] = (g / l) * sin(x[0]) + u[0] / (m * l * l) - (b / (m * l * l)) * x[1];
+    d[1] = (g / l) * mas_dt_sin(x[0]) + u[0] / (m * l * l) - (b / (m * l * l)) * x[1];
   }
   MAS_HD static double stage_cost(const double* x, const double* u, int k, const ModelParams& P) {
     const double g = 9.81, l = 1.0, m = 1.0, mgl = m * g * l, E_des = mgl;
@@ -129,15 +133,15 @@ struct Pendulum {
     const double w_shape_k = w_shape * (0.2 + 0.8 * late);
     const double w_omega_k = w_omega * (0.2 + 0.8 * late);
     const double Tk = 0.5 * m * l * l * omega * omega;
-    const double V = mgl * cos(theta);
+    const double V = mgl * mas_dt_cos(theta);
     const double E = Tk + V;
     const double energy_error = (E - E_des) / mgl;
-    const double upright_error = 1.0 - cos(theta);
+    const double upright_error = 1.0 - mas_dt_cos(theta);
     return w_energy_k * energy_error * energy_error + w_shape_k * upright_error + w_omega_k * omega * omega + w_u * torque * torque;
   }
   MAS_HD static double terminal_cost(const double* x, const ModelParams&) {
     const double wT_pos = 500.0, wT_vel = 100.0;
-    const double upright_error = 1.0 - cos(x[0]);
+    const double upright_error = 1.0 - mas_dt_cos(x[0]);
     return wT_pos * upright_error + wT_vel * x[1] * x[1];
   }
 };
@@ -165,14 +169,14 @@ struct SingleTrackLane {
   MAS_HD static void A(const double* x, const double* u, double* M, const ModelParams& P) {
     const double psi = x[2], v = x[3], delta = u[0], L = P.p[6];
     MAS_UNROLL for (int i = 0; i < 16; ++i) M[i] = 0.0;
-    M[2 * 4 + 0] = -v * sin(psi); M[3 * 4 + 0] = cos(psi);
-    M[2 * 4 + 1] = v * cos(psi);  M[3 * 4 + 1] = sin(psi);
-    M[3 * 4 + 2] = tan(delta) / L;
+    M[2 * 4 + 0] = -v * mas_dt_sin(psi); M[3 * 4 + 0] = mas_dt_cos(psi);
+    M[2 * 4 + 1] = v * mas_dt_cos(psi);  M[3 * 4 + 1] = mas_dt_sin(psi);
+    M[3 * 4 + 2] = mas_dt_tan(delta) / L;
   }
   MAS_HD static void B(const double* x, const double* u, double* M, const ModelParams& P) {
     const double v = x[3], delta = u[0], L = P.p[6];
     MAS_UNROLL for (int i = 0; i < 8; ++i) M[i] = 0.0;
-    M[0 * 4 + 2] = v / (L * cos(delta) * cos(delta));
+    M[0 * 4 + 2] = v / (L * mas_dt_cos(delta) * mas_dt_cos(delta));
     M[1 * 4 + 3] = 1.0;
   }
   MAS_HD static void lx(const double* x, const double*, int, double* g, const ModelParams& P) { g[0] = 0.0; g[1] = 2.0 * P.p[1] * x[1]; g[2] = 0.0; g[3] = 2.0 * P.p[2] * (x[3] - P.p[0]); }
@@ -200,7 +204,7 @@ struct Bicycle6 {
 
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
     const double psi = x[2], v = x[3], delta = x[4], a = x[5], L = P.p[6];
-    d[0] = v * cos(psi); d[1] = v * sin(psi); d[2] = v * tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
+    d[0] = v * mas_dt_cos(psi); d[1] = v * mas_dt_sin(psi); d[2] = v * mas_dt_tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
   }
   MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
     const double x = s[0], y = s[1], vx = s[3], delta = s[4], a = s[5];

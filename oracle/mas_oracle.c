@@ -26,6 +26,19 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* Transcendental functions of the workload models.  mode 0 (default): the platform libm, as
+ * the reference binary would call it (std::sin/cos/tan).  mode 1: the portable bit-reproducible
+ * implementation of include/mas_dettrig.h, which the HIP path always uses; in this mode the
+ * oracle and the GPU agree to the last bit.  See mas_dettrig.h for why this matters (the
+ * algorithm is chaotic: last-bit differences in sin/cos change converged costs by whole per cents). */
+#include "../include/mas_dettrig.h"
+static int g_trig_mode = 0;
+void mas_oracle_set_trig_mode(int mode) { g_trig_mode = mode; }
+int  mas_oracle_get_trig_mode(void) { return g_trig_mode; }
+static double o_sin(double x) { return g_trig_mode ? mas_dt_sin(x) : sin(x); }
+static double o_cos(double x) { return g_trig_mode ? mas_dt_cos(x) : cos(x); }
+static double o_tan(double x) { return g_trig_mode ? mas_dt_tan(x) : tan(x); }
+
 static double* dalloc(size_t n) {
   double* p = (double*)calloc(n ? n : 1, sizeof(double));
   if (!p) { fprintf(stderr, "mas_oracle: out of memory\n"); abort(); }
@@ -955,7 +968,7 @@ double mas_run_centralized_blocked(mas_ocp** ocps, int n, int max_iterations, do
  * params: [0] track_radius [1] target_velocity [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L */
 static void st_dynamics(const mas_ocp* o, const double* x, const double* u, double* d) {
   const double psi = x[2], v = x[3], delta = u[0], a = u[1], L = o->params[6];
-  d[0] = v * cos(psi); d[1] = v * sin(psi); d[2] = v * tan(delta) / L; d[3] = a;
+  d[0] = v * o_cos(psi); d[1] = v * o_sin(psi); d[2] = v * o_tan(delta) / L; d[3] = a;
 }
 /* examples/multi_agent_single_track.cpp:54-64 */
 static double st_stage(const mas_ocp* o, const double* s, const double* c, size_t t) {
@@ -994,7 +1007,7 @@ static void lqr_vxx(const mas_ocp* o, const double* x, double* H) { (void)x; con
 static void pend_dynamics(const mas_ocp* o, const double* x, const double* u, double* d) {
   (void)o; const double g = 9.81, l = 1.0, m = 1.0, b = 0.1;
   d[0] = x[1];
-  d[1] = (g / l) * sin(x[0]) + u[0] / (m * l * l) - (b / (m * l * l)) * x[1];
+  d[1] = (g / l) * o_sin(x[0]) + u[0] / (m * l * l) - (b / (m * l * l)) * x[1];
 }
 static double pend_stage(const mas_ocp* o, const double* x, const double* u, size_t k) {
   const double g = 9.81, l = 1.0, m = 1.0, mgl = m * g * l, E_des = mgl;
@@ -1007,15 +1020,15 @@ static double pend_stage(const mas_ocp* o, const double* x, const double* u, siz
   const double w_shape_k = w_shape * (0.2 + 0.8 * late);
   const double w_omega_k = w_omega * (0.2 + 0.8 * late);
   const double Tk = 0.5 * m * l * l * omega * omega;
-  const double V = mgl * cos(theta);
+  const double V = mgl * o_cos(theta);
   const double E = Tk + V;
   const double energy_error = (E - E_des) / mgl;
-  const double upright_error = 1.0 - cos(theta);
+  const double upright_error = 1.0 - o_cos(theta);
   return w_energy_k * energy_error * energy_error + w_shape_k * upright_error + w_omega_k * omega * omega + w_u * torque * torque;
 }
 static double pend_terminal(const mas_ocp* o, const double* x) {
   (void)o; const double wT_pos = 500.0, wT_vel = 100.0;
-  const double upright_error = 1.0 - cos(x[0]);
+  const double upright_error = 1.0 - o_cos(x[0]);
   return wT_pos * upright_error + wT_vel * x[1] * x[1];
 }
 
@@ -1032,14 +1045,14 @@ static double lane_stage(const mas_ocp* o, const double* s, const double* c, siz
 static void lane_A(const mas_ocp* o, const double* x, const double* u, double* A) {
   const double psi = x[2], v = x[3], delta = u[0], L = o->params[6];
   for (int i = 0; i < 16; ++i) A[i] = 0.0;
-  A[2 * 4 + 0] = -v * sin(psi); A[3 * 4 + 0] = cos(psi);
-  A[2 * 4 + 1] = v * cos(psi);  A[3 * 4 + 1] = sin(psi);
-  A[3 * 4 + 2] = tan(delta) / L;
+  A[2 * 4 + 0] = -v * o_sin(psi); A[3 * 4 + 0] = o_cos(psi);
+  A[2 * 4 + 1] = v * o_cos(psi);  A[3 * 4 + 1] = o_sin(psi);
+  A[3 * 4 + 2] = o_tan(delta) / L;
 }
 static void lane_B(const mas_ocp* o, const double* x, const double* u, double* B) {
   const double v = x[3], delta = u[0], L = o->params[6];
   for (int i = 0; i < 8; ++i) B[i] = 0.0;
-  B[0 * 4 + 2] = v / (L * cos(delta) * cos(delta));
+  B[0 * 4 + 2] = v / (L * o_cos(delta) * o_cos(delta));
   B[1 * 4 + 3] = 1.0;
 }
 static void lane_lx(const mas_ocp* o, const double* x, const double* u, size_t t, double* g) { (void)u; (void)t; const double* p = o->params; g[0] = 0.0; g[1] = 2.0 * p[1] * x[1]; g[2] = 0.0; g[3] = 2.0 * p[2] * (x[3] - p[0]); }
@@ -1054,7 +1067,7 @@ static void lane_luu(const mas_ocp* o, const double* x, const double* u, size_t 
  * params: [0] R [1] vt [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L [7] w_rate */
 static void b6_dynamics(const mas_ocp* o, const double* x, const double* u, double* d) {
   const double psi = x[2], v = x[3], delta = x[4], a = x[5], L = o->params[6];
-  d[0] = v * cos(psi); d[1] = v * sin(psi); d[2] = v * tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
+  d[0] = v * o_cos(psi); d[1] = v * o_sin(psi); d[2] = v * o_tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
 }
 static double b6_stage(const mas_ocp* o, const double* s, const double* c, size_t t) {
   (void)t; const double* p = o->params;

@@ -206,6 +206,9 @@ double mas_oracle_solve_batch(int model_id, const double* params, int N, int T, 
                               int strategy, int max_outer, int max_iterations, double tolerance, double max_ms,
                               int threads, mas_strategy_stats* stats);
 int mas_oracle_max_threads(void);
+/* 0 = platform libm (faithful to a glibc-linked reference binary), 1 = include/mas_dettrig.h */
+void mas_oracle_set_trig_mode(int mode);
+int  mas_oracle_get_trig_mode(void);
 
 #ifdef __cplusplus
 }

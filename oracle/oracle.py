@@ -35,7 +35,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("mas_oracle.c", "mas_oracle.h", "ref_unit_cases.c", "Makefile")):
+            for f in ("mas_oracle.c", "mas_oracle.h", "ref_unit_cases.c", "Makefile", "../include/mas_dettrig.h")):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         _lib.mas_model_dims.argtypes = [C.c_int, i, i, i]
         _lib.mas_model_default_params.argtypes = [C.c_int, C.c_int, d]
         _lib.mas_oracle_max_threads.restype = C.c_int
+        _lib.mas_oracle_set_trig_mode.argtypes = [C.c_int]
+        _lib.mas_oracle_get_trig_mode.restype = C.c_int
         for name in ("mas_ref_case_initialize", "mas_ref_case_update_initial", "mas_ref_case_global",
                      "mas_ref_case_fd_gradient"):
             getattr(_lib, name).argtypes = [d]
@@ -87,6 +89,16 @@ def default_params(model_id: int, T: int) -> np.ndarray:
     p = np.zeros(16)
     lib().mas_model_default_params(model_id, T, _p(p))
     return p
+
+
+def set_trig_mode(mode: str) -> None:
+    """'libm': platform sin/cos/tan, as a glibc-linked reference binary calls them (default).
+    'det': include/mas_dettrig.h, the bit-reproducible implementation the HIP path uses."""
+    lib().mas_oracle_set_trig_mode({"libm": 0, "det": 1}[mode])
+
+
+def get_trig_mode() -> str:
+    return "det" if lib().mas_oracle_get_trig_mode() else "libm"
 
 
 def max_threads() -> int:

@@ -1,0 +1,67 @@
+"""The C-ABI library builds for gfx950, loads, and exports exactly what include/mas_hip.h
+declares.  No compute call is made (CPU-only machine)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mas_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mas_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_the_same_entry_points():
+    from multi_agent_solver_amd import _capi
+    assert _declared() == sorted(_capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(product_lib):
+    for name in _declared():
+        assert hasattr(product_lib, name), name
+    assert product_lib.mas_hip_abi_version() == 1
+
+
+def test_model_registry_dims(product_lib):
+    nx, nu = C.c_int(), C.c_int()
+    expected = {1: (4, 2), 2: (4, 4), 3: (2, 1), 4: (4, 2), 5: (6, 2)}
+    for mid, dims in expected.items():
+        assert product_lib.mas_hip_model_dims(mid, C.byref(nx), C.byref(nu)) == 0
+        assert (nx.value, nu.value) == dims
+    assert product_lib.mas_hip_model_dims(99, C.byref(nx), C.byref(nu)) != 0
+
+
+def test_code_object_targets_gfx950():
+    import subprocess
+    import __graft_entry__ as g
+    lib = g.build_hip()
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={lib}"],
+                         capture_output=True, text=True)
+    if out.returncode != 0:   # fall back to a byte search for the target id
+        assert b"gfx950" in open(lib, "rb").read()
+    else:
+        assert "gfx950" in out.stdout or b"gfx950" in open(lib, "rb").read()
+
+
+def test_no_cpu_fallback_without_a_gpu(product_lib):
+    """Without a HIP device create() must fail loudly (MAS_HIP_ERR_NO_DEVICE), never compute on the CPU."""
+    if product_lib.mas_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from multi_agent_solver_amd import _capi
+    from multi_agent_solver_amd.batch import BatchSolver
+    with pytest.raises(_capi.MasHipError) as e:
+        BatchSolver(1, 4, 10, 0.5, lib=product_lib)
+    assert e.value.code == _capi.ERR_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multi_agent_solver_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "mas_oracle" not in text, f

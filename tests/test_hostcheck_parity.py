@@ -1,0 +1,117 @@
+"""Host logic + lane arithmetic of the product sources, replayed on the CPU (tests/hostcheck,
+-DMAS_HOST_EMULATION) and compared with the independent oracle.  Same libm on both sides, so
+agreement is BIT-EXACT: costs, trajectories, iteration counts and regularisation events.
+The HIP build of the same sources is checked on the GPU by tests/test_gpu_parity.py."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import run_batch
+
+
+def _same(e, o, total_exact=True):
+    assert np.array_equal(e["cost"], o["cost"])
+    assert np.array_equal(e["X"], o["X"])
+    assert np.array_equal(e["U"], o["U"])
+    assert e["iters"].tolist() == o["iters"].tolist()
+    assert e["stats"]["reg_events"] == o["stats"]["reg_events"]
+    if total_exact:
+        assert e["total_cost"] == o["total_cost"]
+    else:
+        assert abs(e["total_cost"] - o["total_cost"]) <= 1e-12 * abs(o["total_cost"])
+
+
+@pytest.mark.parametrize("strategy", ["single", "sequential", "trustregion", "linesearch"])
+def test_single_track_h100_strategies(hostcheck_lib, oracle, strategy):
+    x0 = oracle.single_track_x0(8)
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy=strategy)
+    _same(e, o)
+    assert e["stats"]["agent_iterations"] == int(o["iters"].sum())
+
+
+def test_single_track_centralized_blocked(hostcheck_lib, oracle):
+    x0 = oracle.single_track_x0(8)
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, "centralized")
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy="centralized")
+    _same(e, o, total_exact=False)   # merit summed agent-major here, step-major in the oracle
+
+
+def test_ragged_agent_count_and_padding(hostcheck_lib, oracle):
+    x0 = oracle.single_track_x0(70)     # 70 agents -> padded to 128 lanes
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 20, 0.5, "sequential", max_outer=3)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 20, 0.5, strategy="sequential", max_outer=3)
+    _same(e, o)
+
+
+def test_single_agent_and_short_horizon(hostcheck_lib, oracle):
+    x0 = oracle.single_track_x0(1)
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 1, 0.5, "single")
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 1, 0.5, strategy="single")
+    _same(e, o)
+
+
+def test_lqr_identity_sequential(hostcheck_lib, oracle):
+    x0 = oracle.lqr_x0(3)
+    e = run_batch(hostcheck_lib, oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, "sequential")
+    o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, strategy="sequential")
+    _same(e, o)
+    assert e["iters"].tolist() == [109, 109, 109]      # first solve hits max_iterations=100, then 9 x 1
+
+
+@pytest.mark.parametrize("T", [50, 60])
+def test_pendulum_plumbing_config(hostcheck_lib, oracle, T):
+    x0, U0 = oracle.pendulum_problem(T, 0.05)
+    e = run_batch(hostcheck_lib, oracle.MODEL_PENDULUM, x0, U0, T, 0.05, "single", max_iterations=1000, tolerance=1e-4)
+    o = oracle.solve_batch(oracle.MODEL_PENDULUM, x0, U0, T, 0.05, strategy="single", max_iterations=1000, tolerance=1e-4)
+    _same(e, o)
+
+
+def test_lane_following_analytic_derivatives(hostcheck_lib, oracle):
+    x0 = np.array([[0.0, 1.0, 0.0, 0.0]])
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK_LANE, x0, None, 80, 0.1, "single", max_iterations=10)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK_LANE, x0, None, 80, 0.1, strategy="single", max_iterations=10)
+    _same(e, o)
+
+
+def test_bicycle6_trust_region(hostcheck_lib, oracle):
+    x0 = oracle.bicycle6_x0(4)
+    e = run_batch(hostcheck_lib, oracle.MODEL_BICYCLE6, x0, None, 200, 0.25, "trustregion")
+    o = oracle.solve_batch(oracle.MODEL_BICYCLE6, x0, None, 200, 0.25, strategy="trustregion")
+    _same(e, o)
+
+
+def test_staged_backward_pass(hostcheck_lib, oracle):
+    """linearisation sweep + Riccati recursion outputs, stage by stage"""
+    from multi_agent_solver_amd.batch import BatchSolver
+    x0 = oracle.single_track_x0(5)
+    rng = np.random.default_rng(1)
+    U = 0.3 * rng.standard_normal((5, 30, 2))
+    with BatchSolver(oracle.MODEL_SINGLE_TRACK, 5, 30, 0.5, lib=hostcheck_lib) as s:
+        s.set_initial_states(x0)
+        s.set_controls(U)
+        s.initialize_problem()
+        got = s.debug_backward()
+    for a in range(5):
+        ref = oracle.backward_pass(oracle.MODEL_SINGLE_TRACK, x0[a], U[a], 30, 0.5)
+        for name in ("A", "B", "lx", "lu", "lxx", "luu", "lux"):
+            assert np.array_equal(got["derivs"][name][a], ref["derivs"][name]), name
+        assert np.array_equal(got["k"][a], ref["k"])
+        assert np.array_equal(got["K"][a], ref["K"])
+
+
+def test_missing_required_params_raise_like_params_at(hostcheck_lib):
+    from multi_agent_solver_amd.batch import BatchSolver
+    with BatchSolver(1, 2, 5, 0.5, lib=hostcheck_lib) as s:
+        with pytest.raises(KeyError):
+            s.set_params({"max_iterations": 10, "tolerance": 1e-5})     # no max_ms
+
+
+def test_max_iterations_limit_and_status(hostcheck_lib, oracle):
+    x0 = oracle.single_track_x0(4)
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, "single", max_iterations=2)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy="single", max_iterations=2)
+    _same(e, o)
+    assert set(e["status"].tolist()) <= {0, 1}
+    assert (e["iters"] <= 2).all()
