@@ -16,8 +16,8 @@
  * |n| < 2^20, i.e. |x| < 1.6e6), then degree-17 / degree-16 Taylor polynomials on
  * [-pi/4, pi/4] with a first-order correction for the reduction tail; tan = sin / cos.
  * Accuracy against glibc (tests/test_dettrig.py): sin, cos <= 1 ulp, tan <= 3 ulp.
- * Outside the reduction range, and for NaN/Inf, the platform libm is used (not reproducible;
- * no workload in this repository gets there).
+ * Outside the reduction range, and for NaN/Inf, the result is NaN (no workload in this
+ * repository gets there; a silent switch to the platform libm would break reproducibility).
  *
  * Both the product (multi_agent_solver_amd/csrc) and the CPU oracle (oracle/, in its
  * "det" trig mode) include this file, exactly as both would link one libm.
@@ -82,41 +82,49 @@ MAS_DT_FN double mas_dt_kcos(double x, double y) {
   return w + (((1.0 - w) - hz) + ((z * z) * q - x * y));
 }
 
+/* Arguments outside the reduction range (|x| > 1.6e6), NaN and Inf give NaN: a loud, and still
+ * reproducible, answer.  The functions are branch-free (selects only) so that a compiler can
+ * merge identical sub-expressions across the many perturbed evaluations of a finite-difference
+ * sweep. */
 MAS_DT_FN int mas_dt_in_range(double x) { return fabs(x) <= MAS_DT_MAX_ARG; } /* false for NaN */
 
 MAS_DT_FN double mas_dt_sin(double x) {
-  if (!mas_dt_in_range(x)) return sin(x);
+  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
   const double r = (n & 1) ? mas_dt_kcos(y0, y1) : mas_dt_ksin(y0, y1);
-  return (n & 2) ? -r : r;
+  const double v = (n & 2) ? -r : r;
+  return ok ? v : (double)NAN;
 }
 
 MAS_DT_FN double mas_dt_cos(double x) {
-  if (!mas_dt_in_range(x)) return cos(x);
+  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
   const double r = (n & 1) ? mas_dt_ksin(y0, y1) : mas_dt_kcos(y0, y1);
-  return ((n + 1) & 2) ? -r : r;
+  const double v = ((n + 1) & 2) ? -r : r;
+  return ok ? v : (double)NAN;
 }
 
 /* both at once (one reduction); bitwise equal to mas_dt_sin / mas_dt_cos */
 MAS_DT_FN void mas_dt_sincos(double x, double* sn, double* cs) {
-  if (!mas_dt_in_range(x)) { *sn = sin(x); *cs = cos(x); return; }
+  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
   const double s = mas_dt_ksin(y0, y1), c = mas_dt_kcos(y0, y1);
   const double rs = (n & 1) ? c : s, rc = (n & 1) ? s : c;
-  *sn = (n & 2) ? -rs : rs;
-  *cs = ((n + 1) & 2) ? -rc : rc;
+  const double vs = (n & 2) ? -rs : rs, vc = ((n + 1) & 2) ? -rc : rc;
+  *sn = ok ? vs : (double)NAN;
+  *cs = ok ? vc : (double)NAN;
 }
 
 MAS_DT_FN double mas_dt_tan(double x) {
-  if (!mas_dt_in_range(x)) return tan(x);
+  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(x, &y0, &y1);
+  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
   const double s = mas_dt_ksin(y0, y1), c = mas_dt_kcos(y0, y1);
-  return (n & 1) ? -(c / s) : s / c;
+  const double v = (n & 1) ? -(c / s) : s / c;
+  return ok ? v : (double)NAN;
 }
 
 #endif /* MAS_DETTRIG_H */

@@ -50,18 +50,33 @@ struct Backend {
   void zero(void* d, size_t n) { std::memset(d, 0, n); }
   void sync() {}
   void resolve_profile() {}
+  // sub-batch streams (no-ops here: the emulation runs everything in program order)
+  struct Event {};
+  Stream make_stream() { return nullptr; }
+  void drop_stream(Stream) {}
+  Event make_event() { return Event{}; }
+  void drop_event(Event) {}
+  void use(Stream) {}
+  void use_main() {}
+  void record(Event&) {}
+  void wait(Event&) {}
+  void d2h_async(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
 
   template <int BY, class F>
-  void launch_1d(const char* name, const F& f, int n, double alg_bytes = 0.0) {
+  void launch_1d(const char* name, const F& f, int n, double alg_bytes = 0.0) { launch_1d_range<BY>(name, f, 0, n, alg_bytes); }
+  template <int BY, class F>
+  void launch_2d(const char* name, const F& f, int n, int ny, double alg_bytes = 0.0) { launch_2d_range<BY>(name, f, 0, n, ny, alg_bytes); }
+  template <int BY, class F>
+  void launch_1d_range(const char* name, const F& f, int lo, int hi, double alg_bytes = 0.0) {
     auto t0 = std::chrono::steady_clock::now();
-    for (int a = 0; a < n; ++a) f(a);
+    for (int a = lo; a < hi; ++a) f(a);
     account(name, t0, alg_bytes);
   }
   template <int BY, class F>
-  void launch_2d(const char* name, const F& f, int n, int ny, double alg_bytes = 0.0) {
+  void launch_2d_range(const char* name, const F& f, int lo, int hi, int ny, double alg_bytes = 0.0) {
     auto t0 = std::chrono::steady_clock::now();
     for (int y = 0; y < ny; ++y)
-      for (int a = 0; a < n; ++a) f(a, y);
+      for (int a = lo; a < hi; ++a) f(a, y);
     account(name, t0, alg_bytes);
   }
   // one cooperating group of `n` lanes that needs block-wide reductions: emulated serially by
@@ -99,15 +114,15 @@ using Stream = hipStream_t;
 
 // lane x = agent inside a 64-wide group (one wavefront); y = time step / alpha trial
 template <class F>
-__global__ void __launch_bounds__(64) mas_kernel_1d(const F f, int n) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
-  if (a < n) f(a);
+__global__ void __launch_bounds__(64) mas_kernel_1d(const F f, int lo, int hi) {
+  const int a = lo + blockIdx.x * 64 + threadIdx.x;
+  if (a < hi) f(a);
 }
 template <class F, int BY>
-__global__ void __launch_bounds__(64 * BY) mas_kernel_2d(const F f, int n, int ny) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(64 * BY) mas_kernel_2d(const F f, int lo, int hi, int ny) {
+  const int a = lo + blockIdx.x * 64 + threadIdx.x;
   const int y = blockIdx.y * BY + threadIdx.y;
-  if (a < n && y < ny) f(a, y);
+  if (a < hi && y < ny) f(a, y);
 }
 // one workgroup whose lanes cooperate through barriers (centralised strategy); MAXT bounds the
 // block so the register allocator knows how many VGPRs a lane may keep
@@ -117,7 +132,8 @@ __global__ void __launch_bounds__(MAXT) mas_kernel_group(const F f, int n) {
 }
 
 struct Backend {
-  Stream stream = nullptr;
+  Stream stream = nullptr;       // the handle's main stream
+  Stream cur = nullptr;          // stream the next launch / async copy goes to (main or a sub-batch stream)
   bool own_stream = false;
   int device = 0;
   bool profiling = false;
@@ -136,7 +152,20 @@ struct Backend {
     MAS_HIP_CHECK(hipSetDevice(dev));
     if (external_stream) { stream = static_cast<hipStream_t>(external_stream); own_stream = false; }
     else { MAS_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+    cur = stream;
   }
+  // sub-batch streams: independent agent ranges iterate concurrently so that their latency-bound
+  // kernels overlap on the chip
+  using Event = hipEvent_t;
+  Stream make_stream() { Stream s; MAS_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
+  void drop_stream(Stream s) { if (s) (void)hipStreamDestroy(s); }
+  Event make_event() { Event e; MAS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return e; }
+  void drop_event(Event e) { (void)hipEventDestroy(e); }
+  void use(Stream s) { cur = s; }
+  void use_main() { cur = stream; }
+  void record(Event& e) { MAS_HIP_CHECK(hipEventRecord(e, cur)); }
+  void wait(Event& e) { MAS_HIP_CHECK(hipEventSynchronize(e)); }
+  void d2h_async(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, cur)); }
   void destroy() {
     (void)hipSetDevice(device);
     for (auto& p : pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -157,8 +186,8 @@ struct Backend {
   void free_pinned(void* p) { if (p) (void)hipHostFree(p); }
   void h2d(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream)); MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
   void d2h(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream)); MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
-  void d2d(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream)); }
-  void zero(void* d, size_t n) { MAS_HIP_CHECK(hipMemsetAsync(d, 0, n, stream)); }
+  void d2d(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, cur)); }
+  void zero(void* d, size_t n) { MAS_HIP_CHECK(hipMemsetAsync(d, 0, n, cur)); }
   void sync() { MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
 
   hipEvent_t get_event() {
@@ -168,17 +197,16 @@ struct Backend {
   void begin(const char* name, double bytes) {
     if (!profiling) return;
     Pending p; p.name = name; p.bytes = bytes; p.e0 = get_event(); p.e1 = get_event();
-    MAS_HIP_CHECK(hipEventRecord(p.e0, stream));
+    MAS_HIP_CHECK(hipEventRecord(p.e0, cur));
     pending.push_back(p);
   }
   void end() {
     if (!profiling) return;
-    MAS_HIP_CHECK(hipEventRecord(pending.back().e1, stream));
-    if (pending.size() >= 4096) resolve_profile();
+    MAS_HIP_CHECK(hipEventRecord(pending.back().e1, cur));
   }
   void resolve_profile() {
     if (pending.empty()) return;
-    MAS_HIP_CHECK(hipStreamSynchronize(stream));
+    MAS_HIP_CHECK(hipDeviceSynchronize());
     for (auto& p : pending) {
       float ms = 0.f;
       MAS_HIP_CHECK(hipEventElapsedTime(&ms, p.e0, p.e1));
@@ -190,18 +218,22 @@ struct Backend {
   }
 
   template <int BY, class F>
-  void launch_1d(const char* name, const F& f, int n, double alg_bytes = 0.0) {
-    if (n <= 0) return;
+  void launch_1d(const char* name, const F& f, int n, double alg_bytes = 0.0) { launch_1d_range<BY>(name, f, 0, n, alg_bytes); }
+  template <int BY, class F>
+  void launch_2d(const char* name, const F& f, int n, int ny, double alg_bytes = 0.0) { launch_2d_range<BY>(name, f, 0, n, ny, alg_bytes); }
+  template <int BY, class F>
+  void launch_1d_range(const char* name, const F& f, int lo, int hi, double alg_bytes = 0.0) {
+    if (hi <= lo) return;
     begin(name, alg_bytes);
-    hipLaunchKernelGGL((mas_kernel_1d<F>), dim3((n + 63) / 64), dim3(64), 0, stream, f, n);
+    hipLaunchKernelGGL((mas_kernel_1d<F>), dim3((hi - lo + 63) / 64), dim3(64), 0, cur, f, lo, hi);
     MAS_HIP_CHECK(hipGetLastError());
     end();
   }
   template <int BY, class F>
-  void launch_2d(const char* name, const F& f, int n, int ny, double alg_bytes = 0.0) {
-    if (n <= 0 || ny <= 0) return;
+  void launch_2d_range(const char* name, const F& f, int lo, int hi, int ny, double alg_bytes = 0.0) {
+    if (hi <= lo || ny <= 0) return;
     begin(name, alg_bytes);
-    hipLaunchKernelGGL((mas_kernel_2d<F, BY>), dim3((n + 63) / 64, (ny + BY - 1) / BY), dim3(64, BY), 0, stream, f, n, ny);
+    hipLaunchKernelGGL((mas_kernel_2d<F, BY>), dim3((hi - lo + 63) / 64, (ny + BY - 1) / BY), dim3(64, BY), 0, cur, f, lo, hi, ny);
     MAS_HIP_CHECK(hipGetLastError());
     end();
   }
@@ -210,9 +242,9 @@ struct Backend {
     if (n <= 0) return;
     begin(name, alg_bytes);
     const int threads = ((n + 63) / 64) * 64;
-    if (threads <= 256) hipLaunchKernelGGL((mas_kernel_group<F, 256>), dim3(1), dim3(threads), 0, stream, f, n);
-    else if (threads <= 512) hipLaunchKernelGGL((mas_kernel_group<F, 512>), dim3(1), dim3(threads), 0, stream, f, n);
-    else hipLaunchKernelGGL((mas_kernel_group<F, 1024>), dim3(1), dim3(threads), 0, stream, f, n);
+    if (threads <= 256) hipLaunchKernelGGL((mas_kernel_group<F, 256>), dim3(1), dim3(threads), 0, cur, f, n);
+    else if (threads <= 512) hipLaunchKernelGGL((mas_kernel_group<F, 512>), dim3(1), dim3(threads), 0, cur, f, n);
+    else hipLaunchKernelGGL((mas_kernel_group<F, 1024>), dim3(1), dim3(threads), 0, cur, f, n);
     MAS_HIP_CHECK(hipGetLastError());
     end();
   }

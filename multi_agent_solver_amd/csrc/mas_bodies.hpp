@@ -1,10 +1,11 @@
 // mas_bodies.hpp -- kernel bodies of the batched iLQR path over the SoA device layout.
 //
-// Device layout: every per-agent quantity is stored "structure of arrays"
-// with the AGENT index fastest:  element (row r, agent a) of an array with R rows lives at
-// base[r * Np + a], Np = N rounded up to a multiple of 64.  A wavefront's 64 lanes are 64
-// consecutive agents, so each load/store instruction touches 64 consecutive doubles (512 B,
-// fully coalesced) without any LDS staging.  Rows are (t, component) pairs, t-major.
+// Device layout: trajectories, gains and per-agent scalars are stored
+// "structure of arrays" with the AGENT index fastest:  element (row r, agent a) of an array with R
+// rows lives at base[r * Np + a], Np = N rounded up to a multiple of 64.  A wavefront's 64 lanes
+// are 64 consecutive agents, so each load/store instruction touches 64 consecutive doubles (512 B,
+// fully coalesced).  Rows are (t, component) pairs, t-major.  The linearisation output is the
+// exception: it is an array of per-(t, agent) tiles (MAS_TILE_AT below).
 //
 // Each body is a functor called with (agent) or (agent, y); y is a time step (linearisation
 // sweep, commit) or an alpha-trial index (speculative line search).
@@ -24,7 +25,12 @@ struct Dims {
   size_t Np;    // padded agent count (row stride)
 };
 
-#define MAS_AT(base, row, a) (base)[static_cast<size_t>(row) * d.Np + static_cast<size_t>(a)]
+// (uniform row pointer)[lane index]: lets the compiler address with a scalar base + 32-bit lane offset
+#define MAS_AT(base, row, a) ((base) + static_cast<size_t>(row) * d.Np)[static_cast<unsigned>(a)]
+// derivative tiles: one contiguous block of ND doubles per (time step, agent) -- "array of tiles",
+// D[t][agent][ND].  The sweep produces a tile per lane and stages it through LDS so the stores are
+// contiguous; the backward pass consumes 4 consecutive tiles per wavefront as one linear copy.
+#define MAS_TILE_AT(base, ND_, t, a, e) (base)[(static_cast<size_t>(t) * d.Np + static_cast<size_t>(a)) * (ND_) + (e)]
 
 // -------------------------------------------------------------------------------------------
 // integrate_horizon + objective (ilqr.hpp:75-78; ocp.hpp:110,182): one lane per agent.
@@ -63,7 +69,7 @@ template <class M>
 struct SweepBody {
   Dims d; ModelParams P;
   const double* X; const double* U;
-  double* D;             // [T*ND][Np]
+  double* D;             // [T][Np][ND] tiles
   const int* active;
   MAS_HD void operator()(int a, int t) const {
     using L = DerivLayout<M>;
@@ -73,12 +79,14 @@ struct SweepBody {
     MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = MAS_AT(X, t * NX + i, a);
     MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = MAS_AT(U, t * NU + i, a);
     linearise<M>(x, u, t, Dl, P);
-    MAS_UNROLL for (int i = 0; i < L::ND; ++i) MAS_AT(D, t * L::ND + i, a) = Dl[i];
+    MAS_UNROLL for (int i = 0; i < L::ND; ++i) MAS_TILE_AT(D, L::ND, t, a, i) = Dl[i];
   }
 };
 
 // -------------------------------------------------------------------------------------------
-// Backward Riccati recursion (ilqr.hpp:92-193), one lane per agent, sequential in t.
+// Backward Riccati recursion (ilqr.hpp:92-193), one lane per agent, sequential in t.  This scalar
+// form is what the host emulation replays; on the GPU the same recursion runs 16 lanes per agent
+// over LDS tiles (mas_kernels_hip.hpp, BackwardTile), element for element the same arithmetic.
 template <class M>
 struct BackwardBody {
   Dims d; ModelParams P;
@@ -95,9 +103,13 @@ struct BackwardBody {
     MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = MAS_AT(X, d.T * NX + i, a);
     terminal_boundary<M>(xT, vx, vxx, P);
     long long regs = 0;
+    // software pipeline: the derivative rows of step t-1 are requested before step t is
+    // computed, so their HBM latency hides behind ~1000 dependent FP64 instructions
+    double Dl[L::ND], Dn[L::ND];
+    MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = MAS_TILE_AT(D, L::ND, d.T - 1, a, i);
     for (int t = d.T - 1; t >= 0; --t) {
-      double Dl[L::ND];
-      MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = MAS_AT(D, t * L::ND + i, a);
+      const int tn = t > 0 ? t - 1 : 0;
+      MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dn[i] = MAS_TILE_AT(D, L::ND, tn, a, i);
       QFunction<M> q;
       assemble_q<M>(Dl, vx, vxx, q);
       double Lfac[NU * NU], k[NU], K[NU * NX];
@@ -105,6 +117,7 @@ struct BackwardBody {
       gains_and_value<M>(q, Lfac, k, K, vx, vxx);
       MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(kff, t * NU + i, a) = k[i];
       MAS_UNROLL for (int i = 0; i < NU * NX; ++i) MAS_AT(Kfb, t * NU * NX + i, a) = K[i];
+      MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = Dn[i];
     }
     reg_events[a] += regs;
   }
@@ -131,19 +144,29 @@ struct ForwardBody {
     for (int q = 0; q < j; ++q) alpha *= 0.5;
     double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
     double* Uj = Us + static_cast<size_t>(j) * d.T * NU * d.Np;
-    double x[NX], xn[NX], xr[NX], ur[NU], k[NU], K[NU * NX], u[NU];
+    double x[NX], xn[NX], u[NU];
+    // reference point and gains of step t+1 are requested before step t is integrated (software pipeline)
+    double xr[NX], ur[NU], k[NU], K[NU * NX], xr_n[NX], ur_n[NU], k_n[NU], K_n[NU * NX];
     MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(Xj, i, a) = x[i]; }
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = MAS_AT(X, i, a);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) ur[i] = MAS_AT(U, i, a);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) k[i] = MAS_AT(kff, i, a);
+    MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = MAS_AT(Kfb, i, a);
     double c = 0.0;
     for (int t = 0; t < d.T; ++t) {
-      MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = MAS_AT(X, t * NX + i, a);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) ur[i] = MAS_AT(U, t * NU + i, a);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) k[i] = MAS_AT(kff, t * NU + i, a);
-      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = MAS_AT(Kfb, t * NU * NX + i, a);
+      const int tn = t + 1 < d.T ? t + 1 : t;
+      MAS_UNROLL for (int i = 0; i < NX; ++i) xr_n[i] = MAS_AT(X, tn * NX + i, a);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) ur_n[i] = MAS_AT(U, tn * NU + i, a);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) k_n[i] = MAS_AT(kff, tn * NU + i, a);
+      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K_n[i] = MAS_AT(Kfb, tn * NU * NX + i, a);
       forward_control<M>(x, xr, ur, k, K, alpha, clamp, lb, ub, u);
       MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(Uj, t * NU + i, a) = u[i];
       c += M::stage_cost(x, u, t, P);
       rk4_step<M>(x, u, dt, xn, P);
       MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(Xj, (t + 1) * NX + i, a) = x[i]; }
+      MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = xr_n[i];
+      MAS_UNROLL for (int i = 0; i < NU; ++i) { ur[i] = ur_n[i]; k[i] = k_n[i]; }
+      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = K_n[i];
     }
     c += M::terminal_cost(x, P);
     trial_merit[static_cast<size_t>(j) * d.Np + a] = c;
@@ -290,6 +313,14 @@ struct AosToSoaBody {
   const double* aos; double* soa; int cols;
   MAS_HD void operator()(int a, int c) const {
     for (int r = 0; r < rows; ++r) MAS_AT(soa, c * rows + r, a) = aos[(static_cast<size_t>(a) * cols + c) * rows + r];
+  }
+};
+// derivative tiles [T][Np][ND] -> host layout [N][T][ND] (parity tests only)
+struct TilesToHostBody {
+  Dims d; int nd;
+  const double* tiles; double* out;
+  MAS_HD void operator()(int a, int t) const {
+    for (int e = 0; e < nd; ++e) out[(static_cast<size_t>(a) * d.T + t) * nd + e] = MAS_TILE_AT(tiles, nd, t, a, e);
   }
 };
 struct SoaToAosBody {

@@ -63,7 +63,7 @@ struct CentralBackwardBody {
   MAS_HD void assemble(int a, int t, const AgentState& s, QFunction<M>& q) const {
     using L = DerivLayout<M>;
     double Dl[L::ND];
-    MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = MAS_AT(D, t * L::ND + i, a);
+    MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dl[i] = MAS_TILE_AT(D, L::ND, t, a, i);
     assemble_q<M>(Dl, s.vx, s.vxx, q);
   }
   MAS_HD void finish(int a, int t, const QFunction<M>& q, const double* Lfac, AgentState& s) const {

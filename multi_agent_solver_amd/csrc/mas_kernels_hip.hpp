@@ -1,0 +1,280 @@
+// mas_kernels_hip.hpp -- the two hand-shaped gfx950 kernels of the iteration (HIP build only).
+//
+//  * mas_sweep_kernel      linearisation sweep, one lane per (agent, t).  Each lane produces one
+//                          derivative tile (ND doubles) in registers; the wavefront stages the tiles
+//                          through LDS in 16-element chunks so that every global store instruction
+//                          writes contiguous 128-byte runs of the [t][agent][ND] tile array.
+//  * mas_backward_tile_kernel  backward Riccati recursion with SIXTEEN lanes per agent (a wavefront =
+//                          4 agents): the small dense products of ilqr.hpp:115-119,183-192 are spread
+//                          element-wise over the 16 lanes, operands live in an LDS tile per agent.
+//                          The recursion is a dependency chain in t; per lane it is ~5x shorter than
+//                          the one-lane-per-agent form (BackwardBody), which remains the host-emulated
+//                          statement of the same arithmetic: every output element is the same sequence
+//                          of multiplies and adds (sums in k order from 0.0), so results are bit-equal.
+//
+// No MFMA: v_mfma_f64_4x4x4 fuses the multiply-adds of a dot product, the reference (SSE2, no FMA;
+// CMakeLists.txt sets no -march) rounds after every multiply -- and the algorithm amplifies last-bit
+// differences chaotically (include/mas_dettrig.h), so a fused product would break parity.
+#pragma once
+
+#include "mas_bodies.hpp"
+
+namespace mas {
+
+// ------------------------------------------------------------------------- sweep --------
+template <class M>
+__global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ U,
+                                                        double* __restrict__ D, const int* __restrict__ active, int lo, int n) {
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
+  constexpr int CH = 16;              // tile elements staged per pass
+  constexpr int PITCH = CH + 1;       // odd pitch: the 16 lanes of a ds_write_b64 group hit distinct banks
+  __shared__ double stage[4][64 * PITCH];
+
+  const int lane = threadIdx.x, w = threadIdx.y;
+  const int a0 = lo + blockIdx.x * 64, a = a0 + lane;       // lo is a multiple of 64
+  const int t = blockIdx.y * 4 + w;
+  if (t >= d.T) return;                                    // wave-uniform
+  const bool act = (a < n) && active[a] != 0;
+  const unsigned long long mask = __ballot(act);
+  if (mask == 0ull) return;                                // wave-uniform: nothing to linearise in this group
+
+  double Dl[ND];
+  if (act) {
+    double x[NX], u[NU];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = MAS_AT(X, t * NX + i, a);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = MAS_AT(U, t * NU + i, a);
+    linearise<M>(x, u, t, Dl, P);
+  } else {
+    MAS_UNROLL for (int i = 0; i < ND; ++i) Dl[i] = 0.0;
+  }
+
+  double* st = stage[w];
+  double* tiles = D + (static_cast<size_t>(t) * d.Np + a0) * ND;   // 64 consecutive tiles
+  MAS_UNROLL for (int c0 = 0; c0 < ND; c0 += CH) {
+    constexpr int dummy = 0; (void)dummy;
+    const int cw = (ND - c0 < CH) ? (ND - c0) : CH;                // compile-time after unrolling
+    __builtin_amdgcn_wave_barrier();
+    MAS_UNROLL for (int e = 0; e < CH; ++e) { if (e < cw) st[lane * PITCH + e] = Dl[c0 + e]; }
+    __builtin_amdgcn_wave_barrier();                                // LDS ops of one wave complete in order
+    MAS_UNROLL for (int k = 0; k < CH; ++k) {
+      if (k < cw) {
+        const int idx = k * 64 + lane;                              // linear index into the 64 x cw chunk
+        const int ag = idx / cw, e = idx - ag * cw;
+        if ((mask >> ag) & 1ull) tiles[static_cast<size_t>(ag) * ND + c0 + e] = st[ag * PITCH + e];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward, 16 lanes/agent --
+template <class M>
+struct BackwardTileLayout {
+  using L = DerivLayout<M>;
+  static constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
+  static constexpr int oD = 0, oV = oD + ND, oVx = oV + NX * NX, oAtV = oVx + NX, oBtV = oAtV + NX * NX, oQx = oBtV + NU * NX,
+                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, kEnd = oQuu + NU * NU;
+  static constexpr int STRIDE = (kEnd % 32 == 0) ? kEnd + 2 : kEnd;     // keep agents on different LDS banks
+};
+
+// Per time step the wavefront makes three passes over its four LDS tiles, every lane running the
+// same instruction stream on its own operand addresses (no divergence inside a pass):
+//   pass 1   A^T V, B^T V, q_x, q_u                       (length-NX dot products)
+//   pass 2   q_xx, q_ux, q_uu                             (length-NX dot products)
+//   pass 3   LLT + regularisation ladder, Quu^-1, gains, value update, symmetrisation -- all in
+//            registers: each lane rebuilds the two gain columns and the two rows of K^T q_uu it needs,
+//            evaluates its own and its mirror entry of v_xx and applies the reference's aliased
+//            in-place symmetrisation rule, so no further exchange is needed.
+template <class M>
+__global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
+                                                               double* __restrict__ kff, double* __restrict__ Kfb,
+                                                               long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n) {
+  using TL = BackwardTileLayout<M>;
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
+  constexpr int APW = 4, LPA = 16;                  // agents per wavefront, lanes per agent
+  constexpr int CNT = APW * ND, NREG = (CNT + 63) / 64;
+  __shared__ double lds[APW * TL::STRIDE];
+
+  const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid >> 4;
+  const int a0 = lo + blockIdx.x * APW, a = a0 + slot;
+  const bool valid = (a < n) && active[a] != 0;
+  if (__ballot(valid) == 0ull) return;              // uniform for the (single-wave) block
+  double* T = lds + slot * TL::STRIDE;
+
+  if (!valid) {                                     // idle slot: benign operands so its lanes leave the ladder at once
+    for (int e = lane; e < TL::STRIDE; e += LPA) T[e] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NU) T[TL::oQuu + lane * NU + lane] = 1.0;
+  }
+  if (valid && lane == 0) {                         // terminal boundary condition, ilqr.hpp:92-102
+    double xT[NX], vx[NX], vxx[NX * NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = MAS_AT(X, d.T * NX + i, a);
+    terminal_boundary<M>(xT, vx, vxx, P);
+    MAS_UNROLL for (int i = 0; i < NX; ++i) T[TL::oVx + i] = vx[i];
+    MAS_UNROLL for (int i = 0; i < NX * NX; ++i) T[TL::oV + i] = vxx[i];
+  }
+
+  // ---- loop-invariant operand addresses of this lane's work items (tile-relative, in doubles)
+  constexpr int W1 = NX * NX + NU * NX + NX + NU, R1 = (W1 + LPA - 1) / LPA;
+  constexpr int W2 = NX * NX + NU * NX + NU * NU, R2 = (W2 + LPA - 1) / LPA;
+  int p1[R1], q1[R1], b1[R1], o1[R1];              // pass 1: out = [bias +] sum_k T[p+k] * T[q+k]
+  MAS_UNROLL for (int r = 0; r < R1; ++r) {
+    const int w = lane + r * LPA;
+    int pa = 0, qa = 0, ba = -1, oa = -1;
+    if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
+    else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
+    else if (w < NX * NX + NU * NX + NX) { const int i = w - NX * NX - NU * NX; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }
+    else if (w < W1) { const int i = w - NX * NX - NU * NX - NX; pa = TL::oD + L::oB + i * NX; qa = TL::oVx; ba = TL::oD + L::oLu + i; oa = TL::oQu + i; }
+    p1[r] = pa; q1[r] = qa; b1[r] = ba; o1[r] = oa;
+  }
+  int p2[R2], ps2[R2], q2[R2], b2[R2], o2[R2];     // pass 2: out = bias + sum_k T[p + k*ps] * T[q+k]
+  MAS_UNROLL for (int r = 0; r < R2; ++r) {
+    const int w = lane + r * LPA;
+    int pa = 0, ps = 1, qa = 0, ba = 0, oa = -1;
+    if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oAtV + i; ps = NX; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLxx + w; oa = TL::oQxx + w; }
+    else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLux + e; oa = TL::oQux + e; }
+    else if (w < W2) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
+    p2[r] = pa; ps2[r] = ps; q2[r] = qa; b2[r] = ba; o2[r] = oa;
+  }
+
+  // software pipeline: the four tiles of step t-1 travel HBM -> registers while step t is computed
+  double pre[NREG];
+  auto fetch = [&](int t) {
+    const double* src = D + (static_cast<size_t>(t) * d.Np + a0) * ND;
+    MAS_UNROLL for (int r = 0; r < NREG; ++r) { const int idx = r * 64 + tid; pre[r] = (idx < CNT) ? src[idx] : 0.0; }
+  };
+  fetch(d.T - 1);
+  long long regs = 0;
+
+  for (int t = d.T - 1; t >= 0; --t) {
+    MAS_UNROLL for (int r = 0; r < NREG; ++r) {
+      const int idx = r * 64 + tid;
+      if (idx < CNT) { const int s = idx / ND; lds[s * TL::STRIDE + TL::oD + (idx - s * ND)] = pre[r]; }
+    }
+    if (t > 0) fetch(t - 1);
+    __syncthreads();
+
+    // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
+    {
+      double res[R1];
+      MAS_UNROLL for (int r = 0; r < R1; ++r) {
+        double s = 0.0;
+        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p1[r] + k] * T[q1[r] + k];
+        const double bias = T[b1[r] < 0 ? 0 : b1[r]];
+        res[r] = (b1[r] < 0) ? s : bias + s;
+      }
+      MAS_UNROLL for (int r = 0; r < R1; ++r) { if (valid && o1[r] >= 0) T[o1[r]] = res[r]; }
+    }
+    __syncthreads();
+    // ---- pass 2 (second factors of ilqr.hpp:117-119)
+    {
+      double res[R2];
+      MAS_UNROLL for (int r = 0; r < R2; ++r) {
+        double s = 0.0;
+        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p2[r] + k * ps2[r]] * T[q2[r] + k];
+        res[r] = T[b2[r]] + s;
+      }
+      MAS_UNROLL for (int r = 0; r < R2; ++r) { if (valid && o2[r] >= 0) T[o2[r]] = res[r]; }
+    }
+    __syncthreads();
+    // ---- pass 3 (ilqr.hpp:172-192)
+    {
+      double quu[NU * NU], qu[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU];
+      MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
+      MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
+
+      // LLT + x10 regularisation ladder (:172-182), the 16 lanes of an agent trying 16 consecutive
+      // rungs at once: lane r adds reg_0 .. reg_{r-1} to the diagonal in the reference's order (so
+      // its matrix is bit-identical to what the sequential ladder holds at rung r) and factorises it;
+      // the first lane that succeeds is the rung the sequential loop would have stopped at.
+      {
+        double cur[NU * NU];
+        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = quu[i];
+        double reg = 1e-6;
+        for (int q = 0; q < lane; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; reg *= 10.0; }
+        int base = 0, win = -1;
+        for (;;) {
+          MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
+          const int ok = llt_compute<NU>(Lfac) == 0;
+          const unsigned long long okmask = __ballot(ok);
+          const unsigned field = static_cast<unsigned>(okmask >> (slot * LPA)) & 0xFFFFu;
+          if (win < 0 && field != 0u) win = base + __builtin_ctz(field);
+          if (win < 0 && base + LPA > kRegLadderMax) win = base + LPA - 1;     // guard, never reached (see kRegLadderMax)
+          if (__ballot(win < 0) == 0ull) break;                                // every agent of the wavefront is settled
+          if (win < 0) {                                                      // this agent goes on with rungs base+16 .. base+31
+            for (int q = 0; q < LPA; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; reg *= 10.0; }
+            base += LPA;
+          }
+        }
+        if (lane == (win & (LPA - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oAtV + i] = Lfac[i]; }   // oAtV is dead after pass 2
+        if (lane == 0) regs += win;
+        __syncthreads();
+        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oAtV + i];
+      }
+      llt_solve_identity<NU>(Lfac, ninv);                           // Quu_reg^-1, :183
+      MAS_UNROLL for (int i = 0; i < NU * NU; ++i) ninv[i] = -ninv[i];
+      MAS_UNROLL for (int m = 0; m < NU; ++m) {                     // k = -Quu^-1 q_u, :185
+        double s = 0.0;
+        MAS_UNROLL for (int q = 0; q < NU; ++q) s += ninv[q * NU + m] * qu[q];
+        kf[m] = s;
+      }
+      if (valid && lane == 0) { MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_AT(kff, t * NU + m, a) = kf[m]; }
+
+      constexpr int RM = (NX * NX + LPA - 1) / LPA;                  // rounds over the v_xx entries
+      MAS_UNROLL for (int r = 0; r < RM; ++r) {
+        const int w = lane + r * LPA;
+        const bool live = valid && (w < NX * NX);
+        const int i = (w < NX * NX) ? (w % NX) : 0;
+        const int j = (w < NX * NX) ? (w / NX) : 0;
+        double quxi[NU], quxj[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) { quxi[m] = T[TL::oQux + i * NU + m]; quxj[m] = T[TL::oQux + j * NU + m]; }
+        const double qxx_own = T[TL::oQxx + j * NX + i], qxx_mir = T[TL::oQxx + i * NX + j], qx_i = T[TL::oQx + i];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // columns i and j of K = -Quu^-1 q_ux, :186
+          double si = 0.0, sj = 0.0;
+          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += ninv[q * NU + m] * quxi[q]; sj += ninv[q * NU + m] * quxj[q]; }
+          Ki[m] = si; Kj[m] = sj;
+        }
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // rows i and j of K^T q_uu (unregularised)
+          double si = 0.0, sj = 0.0;
+          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += Ki[q] * quu[m * NU + q]; sj += Kj[q] * quu[m * NU + q]; }
+          ktqi[m] = si; ktqj[m] = sj;
+        }
+        // own entry (i,j) and mirror entry (j,i) of v_xx, :190-191
+        double s, own, mir;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * quxj[m];
+        own = qxx_own + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * Kj[m];
+        own = own + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * Kj[m];
+        own = own + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Kj[m] * quxi[m];
+        mir = qxx_mir + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxj[m] * Ki[m];
+        mir = mir + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqj[m] * Ki[m];
+        mir = mir + s;
+        // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: a lower or diagonal
+        // entry averages the old values, an upper entry sees its (already rewritten) mirror
+        const double sym = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));
+        if (live) T[TL::oV + w] = sym;
+        // the lanes of the first tile column (j == 0) also own gain column i and v_x entry i, :186,188-189
+        if (live && j == 0) {
+          MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_AT(Kfb, t * NU * NX + i * NU + m, a) = Ki[m];
+          double vxi;
+          s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * qu[m];
+          vxi = qx_i + s;
+          s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * kf[m];
+          vxi = vxi + s;
+          s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
+          vxi = vxi + s;
+          T[TL::oVx + i] = vxi;
+        }
+      }
+    }
+    // the barrier after the next publish orders these writes before pass 1 reads them
+  }
+  if (valid && lane == 0) reg_events[a] += regs;
+}
+
+}  // namespace mas

@@ -32,13 +32,14 @@ template <class M>
 MAS_HD void rk4_step(const double* x, const double* u, double dt, double* out, const ModelParams& P) {
   constexpr int NX = M::NX;
   double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
-  M::dynamics(x, u, k1, P);
+  const typename M::Ctl c = M::prepare(u, P);      // u is held over the step: its own terms once
+  M::dynamics_c(x, u, c, k1, P);
   MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + (0.5 * dt) * k1[i];
-  M::dynamics(xs, u, k2, P);
+  M::dynamics_c(xs, u, c, k2, P);
   MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + (0.5 * dt) * k2[i];
-  M::dynamics(xs, u, k3, P);
+  M::dynamics_c(xs, u, c, k3, P);
   MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + dt * k3[i];
-  M::dynamics(xs, u, k4, P);
+  M::dynamics_c(xs, u, c, k4, P);
   MAS_UNROLL for (int i = 0; i < NX; ++i) out[i] = x[i] + (dt / 6.0) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
 }
 

@@ -39,13 +39,20 @@ struct SingleTrack {
   static constexpr bool kDefaultBounds = true;
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
 
-  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
-    const double psi = x[2], v = x[3], delta = u[0], a = u[1], L = P.p[6];
-    d[0] = v * mas_dt_cos(psi);
-    d[1] = v * mas_dt_sin(psi);
-    d[2] = v * mas_dt_tan(delta) / L;
+  // the part of f(x,u) that depends on u alone: RK4 evaluates f four times with the same zero-order-
+  // hold control (integrator.hpp:22-25), so tan(delta) is computed once per step, not four times
+  struct Ctl { double tan_delta; };
+  MAS_HD static Ctl prepare(const double* u, const ModelParams&) { return Ctl{mas_dt_tan(u[0])}; }
+  MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl& c, double* d, const ModelParams& P) {
+    const double psi = x[2], v = x[3], a = u[1], L = P.p[6];
+    double sn, cs;
+    mas_dt_sincos(psi, &sn, &cs);
+    d[0] = v * cs;
+    d[1] = v * sn;
+    d[2] = v * c.tan_delta / L;
     d[3] = a;
   }
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) { dynamics_c(x, u, prepare(u, P), d, P); }
   MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
     const double x = s[0], y = s[1], vx = s[3], delta = c[0], a_cmd = c[1];
     const double dist = fabs(sqrt(x * x + y * y) - P.p[0]);
@@ -58,8 +65,13 @@ struct SingleTrack {
 // ---------------------------------------------------------------------------------------
 // Identity LQR: examples/multi_agent_lqr.cpp:21-76 (A=B=Q=R=Qf=I, n_x=n_u=4), every
 // derivative analytic (:35-41,46-71).
+struct NoCtl {};
+
 struct LqrIdentity {
   static constexpr int NX = 4, NU = 4;
+  using Ctl = NoCtl;
+  MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
+  MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl&, double* d, const ModelParams& P) { dynamics(x, u, d, P); }
   static constexpr bool kAnalyticA = true, kAnalyticB = true, kAnalyticLx = true, kAnalyticLu = true,
                         kAnalyticLxx = true, kAnalyticLuu = true, kAnalyticLux = true, kAnalyticTerm = true;
   static constexpr bool kZeroTerminal = false;
@@ -111,6 +123,9 @@ struct LqrIdentity {
 // No analytic hooks are wired by the example => FD.  params: [0] horizon_d (the T in s = k/(T-1)).
 struct Pendulum {
   static constexpr int NX = 2, NU = 1;
+  using Ctl = NoCtl;
+  MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
+  MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl&, double* d, const ModelParams& P) { dynamics(x, u, d, P); }
   static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
                         kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
   static constexpr bool kZeroTerminal = false;
@@ -159,6 +174,9 @@ struct SingleTrackLane {
   static constexpr bool kDefaultBounds = true;
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -0.7; lb[1] = -1.0; ub[0] = 0.7; ub[1] = 1.0; }
 
+  using Ctl = SingleTrack::Ctl;
+  MAS_HD static Ctl prepare(const double* u, const ModelParams& P) { return SingleTrack::prepare(u, P); }
+  MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl& c, double* d, const ModelParams& P) { SingleTrack::dynamics_c(x, u, c, d, P); }
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) { SingleTrack::dynamics(x, u, d, P); }
   MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
     const double y = s[1], vx = s[3], delta = c[0], a_cmd = c[1];
@@ -196,6 +214,9 @@ struct SingleTrackLane {
 // params: [0] R [1] vt [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L [7] w_rate
 struct Bicycle6 {
   static constexpr int NX = 6, NU = 2;
+  using Ctl = NoCtl;
+  MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
+  MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl&, double* d, const ModelParams& P) { dynamics(x, u, d, P); }
   static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
                         kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
   static constexpr bool kZeroTerminal = true;
@@ -204,7 +225,9 @@ struct Bicycle6 {
 
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
     const double psi = x[2], v = x[3], delta = x[4], a = x[5], L = P.p[6];
-    d[0] = v * mas_dt_cos(psi); d[1] = v * mas_dt_sin(psi); d[2] = v * mas_dt_tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
+    double sn, cs;
+    mas_dt_sincos(psi, &sn, &cs);
+    d[0] = v * cs; d[1] = v * sn; d[2] = v * mas_dt_tan(delta) / L; d[3] = a; d[4] = u[0]; d[5] = u[1];
   }
   MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
     const double x = s[0], y = s[1], vx = s[3], delta = s[4], a = s[5];

@@ -18,6 +18,9 @@
 #include "mas_backend.hpp"
 #include "mas_bodies.hpp"
 #include "mas_central.hpp"
+#if !defined(MAS_HOST_EMULATION)
+#include "mas_kernels_hip.hpp"
+#endif
 
 namespace mas {
 
@@ -61,6 +64,7 @@ class SolverBase {
     else if (key == "tolerance") { tolerance = value; has_tolerance = true; }
     else if (key == "max_ms") { max_ms = value; has_max_ms = true; }
     else if (key == "debug") { debug = value > 0.5; }
+    else if (key == "sub_batches") { sub_batches = static_cast<int>(value); }   // extension: concurrent agent ranges (0 = auto)
     else return false;   // penalty*, constraint_tolerance, ... and unknown keys: ignored
     return true;
   }
@@ -74,6 +78,7 @@ class SolverBase {
   double max_ms = std::numeric_limits<double>::infinity();
   bool debug = false;
   bool has_max_iterations = false, has_tolerance = false, has_max_ms = false;
+  int sub_batches = 0;
 };
 
 template <class M>
@@ -104,15 +109,17 @@ class SolverImpl final : public SolverBase {
     x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
     active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
     reg_events = static_cast<long long*>(be.alloc(sizeof(long long) * Np));
-    counters = static_cast<long long*>(be.alloc(sizeof(long long) * 8));
+    counters = static_cast<long long*>(be.alloc(sizeof(long long) * 32));
     central = static_cast<CentralState*>(be.alloc(sizeof(CentralState)));
     const size_t stage_elems = static_cast<size_t>(d.N) * std::max<size_t>(static_cast<size_t>(T + 1) * NX, static_cast<size_t>(T) * std::max(L::ND, NU * NX));
     stage = dalloc(stage_elems);
-    host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 8));
+    host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 32));
     host_central = static_cast<CentralState*>(be.alloc_pinned(sizeof(CentralState)));
     be.sync();
   }
   ~SolverImpl() override {
+    try { be.sync(); } catch (...) {}
+    for (auto& sb : subs) { be.drop_stream(sb.st); be.drop_event(sb.ev); }
     for (void* p : allocations) be.free(p);
     be.free_pinned(host_counters); be.free_pinned(host_central);
     be.destroy();
@@ -124,7 +131,7 @@ class SolverImpl final : public SolverBase {
   void set_initial_states(const double* src, bool device_ptr) override {
     upload(src, static_cast<size_t>(d.N) * NX, device_ptr);
     be.template launch_2d<1>("aos_to_soa", AosToSoaBody{d, NX, stage, x0, 1}, d.N, 1);
-    have_x0 = true; initialized = false;
+    have_x0 = true; initialized = false; rollout_consistent = false;
   }
   void set_controls(const double* src, bool device_ptr) override {
     if (!src) { be.zero(U, sizeof(double) * d.T * NU * d.Np); }
@@ -132,13 +139,13 @@ class SolverImpl final : public SolverBase {
       upload(src, static_cast<size_t>(d.N) * d.T * NU, device_ptr);
       be.template launch_2d<4>("aos_to_soa", AosToSoaBody{d, NU, stage, U, d.T}, d.N, d.T);
     }
-    initialized = false;
+    initialized = false; rollout_consistent = false;
   }
   void initialize_problem() override {
     require(have_x0, "initial states not set");
     be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
     if (!radii) radii = dalloc(d.Np);
-    initialized = true;
+    initialized = true; rollout_consistent = true;
   }
   void save_initial() override {
     be.d2d(x0_saved, x0, sizeof(double) * NX * d.Np); be.d2d(U_saved, U, sizeof(double) * d.T * NU * d.Np); saved = true;
@@ -146,7 +153,8 @@ class SolverImpl final : public SolverBase {
   void restore_initial() override {
     require(saved, "no saved initial state");
     be.d2d(x0, x0_saved, sizeof(double) * NX * d.Np); be.d2d(U, U_saved, sizeof(double) * d.T * NU * d.Np);
-    be.zero(iters_total, sizeof(int) * d.Np); be.zero(reg_events, sizeof(long long) * d.Np);
+    { std::vector<long long> rg(d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N); for (auto v : rg) reg_base += v; }
+    be.zero(iters_total, sizeof(int) * d.Np); be.zero(reg_events, sizeof(long long) * d.Np);   // per-agent counters restart with the problem
     have_x0 = true;
     initialize_problem();
   }
@@ -217,7 +225,8 @@ class SolverImpl final : public SolverBase {
     for (int iter = 0; iter < max_iterations; ++iter) {
       if (timed_out(t0)) { exit_reason = kExitTime; break; }
       const double nact = static_cast<double>(d.N);
-      be.template launch_2d<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, d.N, d.T, sweep_bytes() * nact);
+      stats.agent_iterations += d.N;
+      launch_sweep(sweep_bytes() * nact);
       be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events}, d.N, backward_bytes() * nact);
       be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
@@ -247,9 +256,9 @@ class SolverImpl final : public SolverBase {
     ensure_initialized();
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
     be.zero(reg_events, sizeof(long long) * d.Np);
-    be.template launch_2d<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, d.N, d.T);
-    be.template launch_1d<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, d.N);
-    if (derivs) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, L::ND, D, stage, d.T}, d.N, d.T); download(derivs, static_cast<size_t>(d.N) * d.T * L::ND, false); }
+    launch_sweep(0.0);
+    launch_backward(0.0);
+    if (derivs) { be.template launch_2d<4>("tiles_to_host", TilesToHostBody{d, L::ND, D, stage}, d.N, d.T); download(derivs, static_cast<size_t>(d.N) * d.T * L::ND, false); }
     if (ko) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, kff, stage, d.T}, d.N, d.T); download(ko, static_cast<size_t>(d.N) * d.T * NU, false); }
     if (Ko) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU * NX, Kfb, stage, d.T}, d.N, d.T); download(Ko, static_cast<size_t>(d.N) * d.T * NU * NX, false); }
     if (regs) { std::vector<long long> h(d.N); be.d2h(h.data(), reg_events, sizeof(long long) * d.N); int64_t s = 0; for (auto v : h) s += v; *regs = s; }
@@ -257,16 +266,15 @@ class SolverImpl final : public SolverBase {
   }
 
   HostStats get_stats() override {
-    std::vector<int> it(d.N); std::vector<long long> rg(d.N);
-    be.d2h(it.data(), iters_total, sizeof(int) * d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N);
-    HostStats s = stats; s.agent_iterations = 0; s.reg_events = 0;
-    for (int v : it) s.agent_iterations += v;
+    std::vector<long long> rg(d.N);
+    be.d2h(rg.data(), reg_events, sizeof(long long) * d.N);
+    HostStats s = stats; s.reg_events = reg_base;
     for (auto v : rg) s.reg_events += v;
     return s;
   }
   void reset_stats() override {
-    stats = HostStats{};
-    be.zero(iters_total, sizeof(int) * d.Np); be.zero(reg_events, sizeof(long long) * d.Np);
+    stats = HostStats{}; reg_base = 0;
+    be.zero(reg_events, sizeof(long long) * d.Np);
   }
 
  private:
@@ -299,6 +307,32 @@ class SolverImpl final : public SolverBase {
   double backward_bytes() const { return 8.0 * d.T * L::ND + 8.0 * NX + 8.0 * d.T * (NU + NU * NX); }
   double forward_bytes() const { return 8.0 * (d.T * (NX + NU + NU + NU * NX) + NX) + 8.0 * ((d.T + 1) * NX + d.T * NU); }
 
+  // linearisation sweep: on the GPU a dedicated kernel that stages each wavefront's tiles through
+  // LDS (mas_kernels_hip.hpp); the host emulation replays the plain body
+  void launch_sweep(double bytes) { launch_sweep(bytes, 0, d.N); }
+  void launch_sweep(double bytes, int lo, int hi) {
+#if defined(MAS_HOST_EMULATION)
+    be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
+#else
+    be.begin("sweep", bytes);
+    hipLaunchKernelGGL((mas_sweep_kernel<M>), dim3((hi - lo + 63) / 64, (d.T + 3) / 4), dim3(64, 4), 0, be.cur, d, P, X, U, D, active, lo, hi);
+    MAS_HIP_CHECK(hipGetLastError());
+    be.end();
+#endif
+  }
+  // backward Riccati pass: 16 lanes per agent over LDS tiles on the GPU, scalar body in the emulation
+  void launch_backward(double bytes) { launch_backward(bytes, 0, d.N); }
+  void launch_backward(double bytes, int lo, int hi) {
+#if defined(MAS_HOST_EMULATION)
+    be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, lo, hi, bytes);
+#else
+    be.begin("backward", bytes);
+    hipLaunchKernelGGL((mas_backward_tile_kernel<M>), dim3((hi - lo + 3) / 4), dim3(64), 0, be.cur, d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
+    MAS_HIP_CHECK(hipGetLastError());
+    be.end();
+#endif
+  }
+
   ForwardBody<M> make_forward() const {
     ForwardBody<M> f;
     f.d = d; f.dt = dt; f.P = P; f.clamp = clamp;
@@ -307,30 +341,86 @@ class SolverImpl final : public SolverBase {
     return f;
   }
 
+  // Agent ranges that iterate concurrently.  Every kernel of the iteration is latency-bound at a few
+  // thousand agents (one wavefront per SIMD or less), so independent ranges on separate HIP streams
+  // overlap almost perfectly; the per-agent arithmetic is untouched.  Range bounds are multiples of 64.
+  struct SubBatch { int lo = 0, hi = 0; long long n_active = 0; bool done = false; Stream st{}; typename Backend::Event ev{}; };
+  void ensure_sub_batches() {
+    int want = sub_batches > 0 ? sub_batches : 1;   // measured on MI355X at 4096 agents: 1 is best (the round is latency-bound per agent)
+    const int groups = static_cast<int>(d.Np / 64);
+    if (want > 8) want = 8;
+    if (want > groups) want = groups;
+    if (want < 1) want = 1;
+    if (static_cast<int>(subs.size()) == want) return;
+    be.sync();
+    for (auto& sb : subs) { be.drop_stream(sb.st); be.drop_event(sb.ev); }
+    subs.clear();
+    for (int k = 0; k < want; ++k) {
+      SubBatch sb;
+      sb.lo = static_cast<int>(static_cast<long long>(groups) * k / want) * 64;
+      sb.hi = static_cast<int>(static_cast<long long>(groups) * (k + 1) / want) * 64;
+      if (sb.hi > d.N) sb.hi = d.N;
+      if (sb.lo >= sb.hi) continue;
+      sb.st = be.make_stream(); sb.ev = be.make_event();
+      subs.push_back(sb);
+    }
+  }
+
   // N x iLQR::solve with per-agent acceptance and termination
   void solve_all() {
     ensure_initialized();
+    ensure_sub_batches();
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
-    // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78)
-    be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
+    // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78).  After
+    // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
+    // rollout and cost (same kernels, same arithmetic, bit for bit), so it is only redone when the
+    // controls were replaced from outside.
+    if (!rollout_consistent) {
+      be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
+      rollout_consistent = true;
+    } else {
+      be.d2d(merit, cost, sizeof(double) * d.Np);   // current_merit = compute_merit(x,u) == objective (ilqr.hpp:78)
+    }
+    be.sync();                                       // fan out: the sub-batch streams start from a settled state
     stats.solves += d.N;
     const auto t0 = std::chrono::steady_clock::now();
-    long long n_active = d.N;
-    for (int iter = 0; iter < max_iterations && n_active > 0; ++iter) {
-      if (timed_out(t0)) { be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N); break; }
-      const double nact = static_cast<double>(n_active);
-      be.template launch_2d<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, d.N, d.T, sweep_bytes() * nact);
-      be.template launch_1d<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, d.N, backward_bytes() * nact);
-      be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
-      be.zero(counters, sizeof(long long) * 2);
-      be.template launch_1d<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
-                                                    iters_total, exit_code, reinterpret_cast<int*>(counters), counters + 1}, d.N);
-      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
-      be.d2h(host_counters, counters, sizeof(long long) * 2);
-      n_active = static_cast<long long>(reinterpret_cast<int*>(host_counters)[0]);
-      stats.converged_solves += host_counters[1];
+    for (auto& sb : subs) { sb.n_active = sb.hi - sb.lo; sb.done = false; }
+    const ForwardBody<M> fwd = make_forward();
+    for (int iter = 0; iter < max_iterations; ++iter) {
+      bool any = false;
+      const bool timeout = timed_out(t0);
+      for (size_t k = 0; k < subs.size(); ++k) {
+        SubBatch& sb = subs[k];
+        if (sb.done) continue;
+        any = true;
+        be.use(sb.st);
+        if (timeout) { be.template launch_1d_range<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, sb.lo, sb.hi); sb.done = true; be.record(sb.ev); continue; }
+        const double nact = static_cast<double>(sb.n_active);
+        stats.agent_iterations += sb.n_active;      // every active agent executes exactly one iLQR iteration per round
+        launch_sweep(sweep_bytes() * nact, sb.lo, sb.hi);
+        launch_backward(backward_bytes() * nact, sb.lo, sb.hi);
+        be.template launch_2d_range<1>("forward", fwd, sb.lo, sb.hi, kNumAlphas, forward_bytes() * nact * kNumAlphas);
+        long long* ctr = counters + 2 * k;
+        be.zero(ctr, sizeof(long long) * 2);
+        be.template launch_1d_range<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
+                                                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1}, sb.lo, sb.hi);
+        be.template launch_2d_range<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, sb.lo, sb.hi, d.T + 1);
+        be.d2h_async(host_counters + 2 * k, ctr, sizeof(long long) * 2);
+        be.record(sb.ev);
+      }
+      if (!any) break;
+      for (size_t k = 0; k < subs.size(); ++k) {     // join: one small read-back per range and round
+        SubBatch& sb = subs[k];
+        if (sb.done) { if (timeout) be.wait(sb.ev); continue; }
+        be.wait(sb.ev);
+        sb.n_active = static_cast<long long>(reinterpret_cast<int*>(host_counters + 2 * k)[0]);
+        stats.converged_solves += host_counters[2 * k + 1];
+        if (sb.n_active == 0) sb.done = true;
+      }
       stats.batch_iterations++;
+      if (timeout) break;
     }
+    be.use_main();
   }
 
   double host_sum(const double* dev) {      // Solution.total_cost: serial sum in block order (nash.hpp:23-37)
@@ -352,8 +442,10 @@ class SolverImpl final : public SolverBase {
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
   CentralState *central = nullptr, *host_central = nullptr;
   std::vector<void*> allocations;
-  bool have_x0 = false, initialized = false, saved = false, last_total_valid = false;
+  bool have_x0 = false, initialized = false, saved = false, last_total_valid = false, rollout_consistent = false;
   double central_total = 0.0;
+  long long reg_base = 0;
+  std::vector<SubBatch> subs;
   HostStats stats;
 };
 
