@@ -17,6 +17,9 @@
 #include <vector>
 
 #include "mas_platform.hpp"
+#if !defined(MAS_HOST_EMULATION)
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: events bound to the dispatch itself (kernel time without launch gaps)
+#endif
 
 namespace mas {
 
@@ -194,15 +197,21 @@ struct Backend {
     if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
     hipEvent_t e; MAS_HIP_CHECK(hipEventCreate(&e)); return e;
   }
+  // When profiling, every launch carries its own start/stop events (hipExtLaunchKernelGGL), i.e. the
+  // time between them is the kernel's execution on the stream -- the quantity rocprofv3 --kernel-trace reports.
   void begin(const char* name, double bytes) {
+    ev0 = nullptr; ev1 = nullptr;
     if (!profiling) return;
     Pending p; p.name = name; p.bytes = bytes; p.e0 = get_event(); p.e1 = get_event();
-    MAS_HIP_CHECK(hipEventRecord(p.e0, cur));
     pending.push_back(p);
+    ev0 = p.e0; ev1 = p.e1;
   }
-  void end() {
-    if (!profiling) return;
-    MAS_HIP_CHECK(hipEventRecord(pending.back().e1, cur));
+  void end() {}
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  template <class K, class... Args>
+  void launch_kernel(K kernel, dim3 grid, dim3 block, Args... args) {
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, cur, ev0, ev1, 0, args...);
+    MAS_HIP_CHECK(hipGetLastError());
   }
   void resolve_profile() {
     if (pending.empty()) return;
@@ -225,16 +234,14 @@ struct Backend {
   void launch_1d_range(const char* name, const F& f, int lo, int hi, double alg_bytes = 0.0) {
     if (hi <= lo) return;
     begin(name, alg_bytes);
-    hipLaunchKernelGGL((mas_kernel_1d<F>), dim3((hi - lo + 63) / 64), dim3(64), 0, cur, f, lo, hi);
-    MAS_HIP_CHECK(hipGetLastError());
+    launch_kernel(mas_kernel_1d<F>, dim3((hi - lo + 63) / 64), dim3(64), f, lo, hi);
     end();
   }
   template <int BY, class F>
   void launch_2d_range(const char* name, const F& f, int lo, int hi, int ny, double alg_bytes = 0.0) {
     if (hi <= lo || ny <= 0) return;
     begin(name, alg_bytes);
-    hipLaunchKernelGGL((mas_kernel_2d<F, BY>), dim3((hi - lo + 63) / 64, (ny + BY - 1) / BY), dim3(64, BY), 0, cur, f, lo, hi, ny);
-    MAS_HIP_CHECK(hipGetLastError());
+    launch_kernel(mas_kernel_2d<F, BY>, dim3((hi - lo + 63) / 64, (ny + BY - 1) / BY), dim3(64, BY), f, lo, hi, ny);
     end();
   }
   template <class F>
@@ -242,10 +249,9 @@ struct Backend {
     if (n <= 0) return;
     begin(name, alg_bytes);
     const int threads = ((n + 63) / 64) * 64;
-    if (threads <= 256) hipLaunchKernelGGL((mas_kernel_group<F, 256>), dim3(1), dim3(threads), 0, cur, f, n);
-    else if (threads <= 512) hipLaunchKernelGGL((mas_kernel_group<F, 512>), dim3(1), dim3(threads), 0, cur, f, n);
-    else hipLaunchKernelGGL((mas_kernel_group<F, 1024>), dim3(1), dim3(threads), 0, cur, f, n);
-    MAS_HIP_CHECK(hipGetLastError());
+    if (threads <= 256) launch_kernel(mas_kernel_group<F, 256>, dim3(1), dim3(threads), f, n);
+    else if (threads <= 512) launch_kernel(mas_kernel_group<F, 512>, dim3(1), dim3(threads), f, n);
+    else launch_kernel(mas_kernel_group<F, 1024>, dim3(1), dim3(threads), f, n);
     end();
   }
 };

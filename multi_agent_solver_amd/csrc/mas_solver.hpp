@@ -315,8 +315,7 @@ class SolverImpl final : public SolverBase {
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
 #else
     be.begin("sweep", bytes);
-    hipLaunchKernelGGL((mas_sweep_kernel<M>), dim3((hi - lo + 63) / 64, (d.T + 3) / 4), dim3(64, 4), 0, be.cur, d, P, X, U, D, active, lo, hi);
-    MAS_HIP_CHECK(hipGetLastError());
+    be.launch_kernel(mas_sweep_kernel<M>, dim3((hi - lo + 63) / 64, (d.T + 3) / 4), dim3(64, 4), d, P, X, U, D, active, lo, hi);
     be.end();
 #endif
   }
@@ -327,8 +326,7 @@ class SolverImpl final : public SolverBase {
     be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, lo, hi, bytes);
 #else
     be.begin("backward", bytes);
-    hipLaunchKernelGGL((mas_backward_tile_kernel<M>), dim3((hi - lo + 3) / 4), dim3(64), 0, be.cur, d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
-    MAS_HIP_CHECK(hipGetLastError());
+    be.launch_kernel(mas_backward_tile_kernel<M>, dim3((hi - lo + 3) / 4), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
     be.end();
 #endif
   }

@@ -1,0 +1,374 @@
+// mas_amd.hpp -- C++ host surface of the MI355X iLQR path, mirroring the reference's API for
+// `--solver ilqr` so that code written against multi_agent_solver reads the same:
+//
+//   reference (include/multi_agent_solver/...)             here (namespace mas_amd)
+//   types.hpp:14-57      State/Control/trajectories         Vector / Matrix (column-major, col(t) contiguous)
+//   ocp.hpp:30-237       struct OCP                         struct OCP  (callbacks -> ModelDescriptor)
+//   solvers/ilqr.hpp     class iLQR {set_params, solve}     class iLQR  (one-agent batch on the GPU)
+//   solvers/solver.hpp   Solver variant, solve, set_params  same names
+//   agent.hpp, solution.hpp, multi_agent_problem.hpp        Agent, AgentPtr, Solution, MultiAgentProblem
+//   strategies/*.hpp     Centralized / SequentialNash / LineSearchNash / TrustRegionNash, Strategy, solve
+//
+// The reference's std::function hooks (types.hpp:21-50) cannot run on a GPU, so an OCP names a
+// REGISTERED model (include/mas_hip.h, enum mas_hip_model) plus its constants instead.  Everything
+// numerical happens behind the C ABI of libmas_hip.so; this header only moves data and keeps the
+// reference's call protocol (who owns what, what solve() reads and writes, which errors are thrown).
+// Header-only, C++17, no Eigen.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <variant>
+#include <vector>
+
+#include "../../../include/mas_hip.h"
+
+namespace mas_amd {
+
+// ---------------------------------------------------------------------------- types ------
+using Vector = std::vector<double>;
+using State = Vector;
+using Control = Vector;
+
+// column-major dense matrix; a trajectory is rows x (T+1) with column t contiguous (types.hpp:14-19)
+struct Matrix {
+  int rows_ = 0, cols_ = 0;
+  std::vector<double> data;
+  Matrix() = default;
+  Matrix(int r, int c, double v = 0.0) : rows_(r), cols_(c), data(static_cast<size_t>(r) * c, v) {}
+  static Matrix Zero(int r, int c) { return Matrix(r, c, 0.0); }
+  int rows() const { return rows_; }
+  int cols() const { return cols_; }
+  size_t size() const { return data.size(); }
+  double& operator()(int r, int c) { return data[static_cast<size_t>(c) * rows_ + r]; }
+  double operator()(int r, int c) const { return data[static_cast<size_t>(c) * rows_ + r]; }
+  double* col(int c) { return data.data() + static_cast<size_t>(c) * rows_; }
+  const double* col(int c) const { return data.data() + static_cast<size_t>(c) * rows_; }
+};
+using StateTrajectory = Matrix;
+using ControlTrajectory = Matrix;
+using SolverParams = std::unordered_map<std::string, double>;   // types.hpp:57
+
+// replaces dynamics / stage_cost / terminal_cost and the optional derivative hooks of the reference OCP
+struct ModelDescriptor {
+  int model_id = 0;                       // enum mas_hip_model
+  std::optional<std::vector<double>> params;   // 16 model constants; nullopt = the example's
+  bool operator==(const ModelDescriptor& o) const { return model_id == o.model_id && params == o.params; }
+};
+
+class HipError : public std::runtime_error {
+ public:
+  HipError(int code, const std::string& what) : std::runtime_error(what), code_(code) {}
+  int code() const { return code_; }
+ private:
+  int code_;
+};
+
+namespace detail {
+
+// one mas_hip_solver handle for a homogeneous batch of agents
+class Batch {
+ public:
+  Batch(const ModelDescriptor& model, int n_agents, int horizon, double dt, const std::optional<Control>& lb,
+        const std::optional<Control>& ub, int device = 0) {
+    mas_hip_problem_desc d{};
+    d.model_id = model.model_id; d.n_agents = n_agents; d.horizon_steps = horizon; d.device = device; d.dt = dt;
+    std::vector<double> p;
+    if (model.params) { p = *model.params; p.resize(16, 0.0); d.params = p.data(); }
+    if (lb && ub) { d.input_lower_bounds = lb->data(); d.input_upper_bounds = ub->data(); }
+    else d.no_input_bounds = 1;             // clamping needs both bounds (ilqr.hpp:213)
+    const int rc = mas_hip_create(&d, &h_);
+    if (rc != MAS_HIP_OK) throw HipError(rc, std::string("mas_hip_create: ") + mas_hip_last_error(nullptr));
+  }
+  ~Batch() { if (h_) mas_hip_destroy(h_); }
+  Batch(const Batch&) = delete;
+  Batch& operator=(const Batch&) = delete;
+  void check(int rc, const char* what) const { if (rc != MAS_HIP_OK) throw HipError(rc, std::string(what) + ": " + mas_hip_last_error(h_)); }
+  void set_params(const SolverParams& params) {
+    for (const auto& kv : params) check(mas_hip_set_param(h_, kv.first.c_str(), kv.second), "mas_hip_set_param");
+  }
+  mas_hip_solver* get() const { return h_; }
+ private:
+  mas_hip_solver* h_ = nullptr;
+};
+
+}  // namespace detail
+
+// ------------------------------------------------------------------------------ OCP ------
+// Mirrors struct OCP (ocp.hpp:30-100).  solve() reads initial_state, best_controls (warm start), dt,
+// dims, input bounds; writes best_states, best_controls, best_cost; never touches initial_* (SURVEY 8(b)).
+struct OCP {
+  StateTrajectory initial_states;
+  ControlTrajectory initial_controls;
+  StateTrajectory best_states;
+  ControlTrajectory best_controls;
+  double best_cost = std::numeric_limits<double>::max();
+
+  State initial_state;
+  ModelDescriptor model;
+
+  int control_dim = 0;
+  int state_dim = 0;
+  int horizon_steps = 0;
+  double dt = 0.0;
+
+  std::optional<Control> input_lower_bounds = std::nullopt;
+  std::optional<Control> input_upper_bounds = std::nullopt;
+
+  size_t id = 0;
+  bool initialized = false;
+
+  // ocp.hpp:102-183: size the guess, roll it out (RK4), set best_* and best_cost.  One-agent GPU call;
+  // MultiAgentProblem::initialize_agents() does the same for all agents in one batch.
+  void initialize_problem() {
+    if (initial_controls.rows() != control_dim || initial_controls.cols() != horizon_steps)
+      initial_controls = ControlTrajectory::Zero(control_dim, horizon_steps);
+    detail::Batch b(model, 1, horizon_steps, dt, input_lower_bounds, input_upper_bounds);
+    b.check(mas_hip_set_initial_states_host(b.get(), initial_state.data()), "set_initial_states");
+    b.check(mas_hip_set_controls_host(b.get(), initial_controls.data.data()), "set_controls");
+    b.check(mas_hip_initialize_problem(b.get()), "initialize_problem");
+    initial_states = StateTrajectory(state_dim, horizon_steps + 1);
+    b.check(mas_hip_get_solution_host(b.get(), initial_states.data.data(), nullptr, &best_cost, nullptr, nullptr), "get_solution");
+    best_states = initial_states;
+    best_controls = initial_controls;
+    initialized = true;
+  }
+  void reset() {                                   // ocp.hpp:83-93
+    initial_controls = ControlTrajectory::Zero(control_dim, horizon_steps);
+    initialize_problem();
+  }
+  void update_initial_with_best() {                // ocp.hpp:95-100
+    initial_controls = best_controls;
+    initial_states = best_states;
+  }
+  bool verify_problem() const {                    // ocp.hpp:187-236 (asserts in the reference)
+    int nx = 0, nu = 0;
+    return state_dim != 0 && control_dim != 0 && horizon_steps != 0 && dt != 0.0 &&
+           static_cast<int>(initial_state.size()) == state_dim && mas_hip_model_dims(model.model_id, &nx, &nu) == MAS_HIP_OK &&
+           nx == state_dim && nu == control_dim &&
+           (!input_lower_bounds || static_cast<int>(input_lower_bounds->size()) == control_dim) &&
+           (!input_upper_bounds || static_cast<int>(input_upper_bounds->size()) == control_dim);
+  }
+};
+
+// ----------------------------------------------------------------------------- iLQR ------
+// class iLQR (solvers/ilqr.hpp:23-55): default-constructible, copyable, set_params + solve.
+class iLQR {
+ public:
+  iLQR() = default;                                // defaults 50 / 1e-6 / inf live in the library (ilqr.hpp:26-37)
+  void set_params(const SolverParams& params) {
+    params.at("max_iterations");                   // the reference uses params.at(): std::out_of_range if absent
+    params.at("tolerance");
+    params.at("max_ms");
+    params_ = params;
+  }
+  const SolverParams& params() const { return params_; }
+
+  void solve(OCP& problem) {                       // ilqr.hpp:58-273 on a one-agent batch
+    detail::Batch b(problem.model, 1, problem.horizon_steps, problem.dt, problem.input_lower_bounds, problem.input_upper_bounds);
+    b.set_params(params_);
+    if (problem.best_controls.rows() != problem.control_dim || problem.best_controls.cols() != problem.horizon_steps)
+      problem.best_controls = ControlTrajectory::Zero(problem.control_dim, problem.horizon_steps);
+    b.check(mas_hip_set_initial_states_host(b.get(), problem.initial_state.data()), "set_initial_states");
+    b.check(mas_hip_set_controls_host(b.get(), problem.best_controls.data.data()), "set_controls");
+    b.check(mas_hip_solve(b.get()), "solve");
+    problem.best_states = StateTrajectory(problem.state_dim, problem.horizon_steps + 1);
+    int32_t it = 0, ex = 0;
+    b.check(mas_hip_get_solution_host(b.get(), problem.best_states.data.data(), problem.best_controls.data.data(), &problem.best_cost, &it, &ex),
+            "get_solution");
+    last_iterations = it; last_exit = ex;
+  }
+  int last_iterations = 0, last_exit = 0;          // extension: the reference exposes neither
+ private:
+  SolverParams params_;
+};
+
+using Solver = std::variant<iLQR>;                 // solvers/solver.hpp:17-22 (cgd / osqp are out of scope)
+inline void solve(Solver& solver, OCP& problem) { std::visit([&](auto& s) { s.solve(problem); }, solver); }
+inline void set_params(Solver& solver, const SolverParams& params) { std::visit([&](auto& s) { s.set_params(params); }, solver); }
+template <typename SolverT>
+std::shared_ptr<Solver> create() { return std::make_shared<Solver>(std::in_place_type<SolverT>); }
+
+// ------------------------------------------------------- agents, problem, solution ------
+struct Agent {                                     // agent.hpp:9-42
+  std::size_t id;
+  std::shared_ptr<OCP> ocp;
+  Agent(std::size_t id_, std::shared_ptr<OCP> ocp_) : id(id_), ocp(std::move(ocp_)) {}
+  int state_dim() const { return ocp->state_dim; }
+  int control_dim() const { return ocp->control_dim; }
+  void reset() { ocp->reset(); }
+  void update_initial_with_best() { ocp->update_initial_with_best(); }
+};
+using AgentPtr = std::shared_ptr<Agent>;
+
+struct Solution {                                  // solution.hpp:9-15
+  std::vector<StateTrajectory> states;
+  std::vector<ControlTrajectory> controls;
+  std::vector<double> costs;
+  double total_cost = 0.0;
+  std::vector<int> iterations;                     // extension: iLQR iterations per agent
+};
+
+struct AgentBlockInfo {                            // multi_agent_problem.hpp:14-22
+  std::size_t agent_id;
+  int state_offset, control_offset, state_dim, control_dim;
+  AgentPtr agent;
+};
+
+class MultiAgentProblem {                          // multi_agent_problem.hpp:24-128
+ public:
+  std::vector<AgentPtr> agents;
+  std::vector<AgentBlockInfo> blocks;
+  void add_agent(const AgentPtr& a) { agents.push_back(a); }
+  void compute_offsets() {                         // :37-50, blocks sorted by agent id
+    blocks.clear();
+    std::vector<AgentPtr> sorted = agents;
+    std::sort(sorted.begin(), sorted.end(), [](const AgentPtr& a, const AgentPtr& b) { return a->id < b->id; });
+    int s_off = 0, u_off = 0;
+    for (auto& a : sorted) {
+      blocks.push_back({a->id, s_off, u_off, a->state_dim(), a->control_dim(), a});
+      s_off += a->state_dim(); u_off += a->control_dim();
+    }
+  }
+};
+
+namespace detail {
+
+// The GPU path batches the id-sorted block list into ONE handle; that needs agents of one model, horizon,
+// step and bound set (true for every reference example).
+inline void require_homogeneous(const MultiAgentProblem& p) {
+  if (p.blocks.empty()) throw std::invalid_argument("MultiAgentProblem has no agents");
+  const OCP& f = *p.blocks.front().agent->ocp;
+  for (const auto& b : p.blocks) {
+    const OCP& o = *b.agent->ocp;
+    if (!(o.model == f.model) || o.horizon_steps != f.horizon_steps || o.dt != f.dt || o.state_dim != f.state_dim ||
+        o.control_dim != f.control_dim || o.input_lower_bounds != f.input_lower_bounds || o.input_upper_bounds != f.input_upper_bounds)
+      throw std::invalid_argument("the HIP iLQR path batches agents of one model / horizon / dt / bounds");
+  }
+}
+
+struct BatchedProblem {
+  std::unique_ptr<Batch> batch;
+  int N = 0, T = 0, nx = 0, nu = 0;
+};
+
+inline BatchedProblem upload(MultiAgentProblem& problem, const SolverParams& params, bool warm_from_best) {
+  require_homogeneous(problem);
+  const OCP& f = *problem.blocks.front().agent->ocp;
+  BatchedProblem bp;
+  bp.N = static_cast<int>(problem.blocks.size()); bp.T = f.horizon_steps; bp.nx = f.state_dim; bp.nu = f.control_dim;
+  bp.batch = std::make_unique<Batch>(f.model, bp.N, bp.T, f.dt, f.input_lower_bounds, f.input_upper_bounds);
+  bp.batch->set_params(params);
+  std::vector<double> x0(static_cast<size_t>(bp.N) * bp.nx), U(static_cast<size_t>(bp.N) * bp.T * bp.nu, 0.0);
+  for (int i = 0; i < bp.N; ++i) {
+    const OCP& o = *problem.blocks[i].agent->ocp;
+    std::copy(o.initial_state.begin(), o.initial_state.end(), x0.begin() + static_cast<size_t>(i) * bp.nx);
+    const ControlTrajectory& src = warm_from_best ? o.best_controls : o.initial_controls;
+    if (src.rows() == bp.nu && src.cols() == bp.T) std::copy(src.data.begin(), src.data.end(), U.begin() + static_cast<size_t>(i) * bp.T * bp.nu);
+  }
+  bp.batch->check(mas_hip_set_initial_states_host(bp.batch->get(), x0.data()), "set_initial_states");
+  bp.batch->check(mas_hip_set_controls_host(bp.batch->get(), U.data()), "set_controls");
+  bp.batch->check(mas_hip_initialize_problem(bp.batch->get()), "initialize_problem");
+  return bp;
+}
+
+// collect_solution (nash.hpp:23-37) + write-back into every OCP
+inline Solution download(MultiAgentProblem& problem, BatchedProblem& bp, bool publish_initial) {
+  const size_t nX = static_cast<size_t>(bp.nx) * (bp.T + 1), nU = static_cast<size_t>(bp.nu) * bp.T;
+  std::vector<double> X(nX * bp.N), U(nU * bp.N), cost(bp.N);
+  std::vector<int32_t> it(bp.N), ex(bp.N);
+  bp.batch->check(mas_hip_get_solution_host(bp.batch->get(), X.data(), U.data(), cost.data(), it.data(), ex.data()), "get_solution");
+  Solution sol;
+  for (int i = 0; i < bp.N; ++i) {
+    OCP& o = *problem.blocks[i].agent->ocp;
+    o.best_states = StateTrajectory(bp.nx, bp.T + 1);
+    o.best_controls = ControlTrajectory(bp.nu, bp.T);
+    std::copy(X.begin() + nX * i, X.begin() + nX * (i + 1), o.best_states.data.begin());
+    std::copy(U.begin() + nU * i, U.begin() + nU * (i + 1), o.best_controls.data.begin());
+    o.best_cost = cost[i];
+    if (publish_initial) o.update_initial_with_best();   // nash.hpp:66-71
+    sol.states.push_back(o.best_states); sol.controls.push_back(o.best_controls); sol.costs.push_back(o.best_cost);
+    sol.iterations.push_back(it[i]);
+  }
+  bp.batch->check(mas_hip_total_cost(bp.batch->get(), &sol.total_cost), "total_cost");
+  return sol;
+}
+
+inline const SolverParams& params_of(const Solver& s) { return std::get<iLQR>(s).params(); }
+
+}  // namespace detail
+
+// OCP::initialize_problem for every agent in one GPU batch (what the examples do in a loop, e.g.
+// examples/multi_agent_single_track.cpp:113-118)
+inline void initialize_agents(MultiAgentProblem& problem) {
+  problem.compute_offsets();
+  for (auto& b : problem.blocks) {
+    OCP& o = *b.agent->ocp;
+    if (o.initial_controls.rows() != o.control_dim || o.initial_controls.cols() != o.horizon_steps)
+      o.initial_controls = ControlTrajectory::Zero(o.control_dim, o.horizon_steps);
+  }
+  SolverParams none;
+  auto bp = detail::upload(problem, none, /*warm_from_best=*/false);
+  Solution s = detail::download(problem, bp, false);
+  for (size_t i = 0; i < problem.blocks.size(); ++i) {
+    OCP& o = *problem.blocks[i].agent->ocp;
+    o.initial_states = o.best_states; o.best_controls = o.initial_controls; o.initialized = true;
+  }
+}
+
+// ----------------------------------------------------------------------- strategies ------
+struct CentralizedStrategy {                       // strategies/centralized.hpp:10-39
+  Solver solver;
+  explicit CentralizedStrategy(Solver s) : solver(std::move(s)) {}
+  Solution operator()(MultiAgentProblem& problem) {
+    problem.compute_offsets();
+    auto bp = detail::upload(problem, detail::params_of(solver), false);
+    bp.batch->check(mas_hip_run_centralized(bp.batch->get()), "run_centralized");
+    return detail::download(problem, bp, false);
+  }
+};
+
+struct SequentialNashStrategy {                    // strategies/nash.hpp:250-268
+  int max_outer; Solver solver_proto; SolverParams params;
+  SequentialNashStrategy(int outer, Solver s, SolverParams p) : max_outer(outer), solver_proto(std::move(s)), params(std::move(p)) {}
+  Solution operator()(MultiAgentProblem& problem) {
+    problem.compute_offsets();
+    auto bp = detail::upload(problem, params, true);
+    bp.batch->check(mas_hip_run_sequential(bp.batch->get(), max_outer), "run_sequential");
+    return detail::download(problem, bp, true);
+  }
+};
+
+struct LineSearchNashStrategy {                    // strategies/nash.hpp:270-288
+  int max_outer; Solver solver_proto; SolverParams params;
+  LineSearchNashStrategy(int outer, Solver s, SolverParams p) : max_outer(outer), solver_proto(std::move(s)), params(std::move(p)) {}
+  Solution operator()(MultiAgentProblem& problem) {
+    problem.compute_offsets();
+    auto bp = detail::upload(problem, params, true);
+    bp.batch->check(mas_hip_run_line_search(bp.batch->get(), max_outer), "run_line_search");
+    return detail::download(problem, bp, true);
+  }
+};
+
+struct TrustRegionNashStrategy {                   // strategies/nash.hpp:290-308
+  int max_outer; Solver solver_proto; SolverParams params;
+  TrustRegionNashStrategy(int outer, Solver s, SolverParams p) : max_outer(outer), solver_proto(std::move(s)), params(std::move(p)) {}
+  Solution operator()(MultiAgentProblem& problem) {
+    problem.compute_offsets();
+    auto bp = detail::upload(problem, params, true);
+    bp.batch->check(mas_hip_run_trust_region(bp.batch->get(), max_outer), "run_trust_region");
+    return detail::download(problem, bp, true);
+  }
+};
+
+using Strategy = std::variant<CentralizedStrategy, SequentialNashStrategy, LineSearchNashStrategy, TrustRegionNashStrategy>;   // strategy.hpp:13
+inline Solution solve(Strategy& strategy, MultiAgentProblem& problem) { return std::visit([&](auto& s) { return s(problem); }, strategy); }
+
+}  // namespace mas_amd

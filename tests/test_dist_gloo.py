@@ -1,0 +1,79 @@
+"""Multi-rank path (bench.py's sharding) rehearsed on the CPU: world_size 2, gloo backend, each
+rank driving the TEST-ONLY host emulation of the kernels on its shard of the agents.  Checks that
+contiguous id-range shards + the scalar reductions bench.py uses reproduce the single-process
+result exactly (agents are decoupled: no data-path collective)."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, T, hostcheck_path, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from bench import shard_range
+    from multi_agent_solver_amd import _capi
+    from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _capi.load(hostcheck_path)
+    lo, hi = shard_range(n_total, world, rank)
+    with BatchSolver(1, hi - lo, T, 0.5, lib=lib) as s:
+        s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+        s.set_initial_states(single_track_x0(hi - lo, first=lo, total=n_total))
+        s.set_controls(None)
+        s.initialize_problem()
+        s.run_sequential(3)
+        sol, st = s.solution(), s.stats()
+    # what bench.py reduces: SUM of iteration counts, MAX of times (here: a stand-in scalar)
+    sums = torch.tensor([float(st["agent_iterations"]), float(sol["cost"].sum())], dtype=torch.float64)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    # optional publish step (nash.hpp:66-71) as an all-gather of the shard costs
+    gathered = [torch.zeros(h - l, dtype=torch.float64) for l, h in (shard_range(n_total, world, r) for r in range(world))]
+    dist.all_gather(gathered, torch.from_numpy(sol["cost"].copy()))
+    if rank == 0:
+        np.savez(out, iters=sums[0].item(), cost_sum=sums[1].item(), tmax=tmax.item(), cost=torch.cat(gathered).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(hostcheck_lib, tmp_path):
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    from conftest import run_batch
+    from multi_agent_solver_amd.batch import single_track_x0
+    n_total, T = 10, 20          # uneven split would be 5/5; use 10 agents on 2 ranks
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker, args=(2, _free_port(), n_total, T, g.HOSTCHECK, out), nprocs=2, join=True)
+    got = np.load(out)
+    ref = run_batch(hostcheck_lib, 1, single_track_x0(n_total), None, T, 0.5, "sequential", max_outer=3)
+    assert np.array_equal(got["cost"], ref["cost"])                 # shard = same agents, same arithmetic
+    assert got["iters"] == ref["stats"]["agent_iterations"]
+    assert got["tmax"] == 2.0
+
+
+def test_shard_ranges_cover_the_block_list():
+    sys.path.insert(0, ROOT)
+    from bench import shard_range
+    for n, w in ((4096, 8), (10, 3), (7, 8), (32768, 8)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

@@ -1,0 +1,91 @@
+"""The C++ host mirror (multi_agent_solver_amd/host) and its example programs: same flags, same
+result line and the same error behaviour as the reference's examples."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe_dir():
+    import __graft_entry__ as g
+    g.build_hip()
+    return g.build_examples()
+
+
+def _run(exe_dir, name, *args):
+    return subprocess.run([os.path.join(exe_dir, name), *args], capture_output=True, text=True, timeout=600)
+
+
+def test_help_lists_names_like_the_reference(exe_dir):
+    r = _run(exe_dir, "multi_agent_single_track", "--help")
+    assert r.returncode == 0
+    assert "Usage: multi_agent_single_track [--agents N] [--solver NAME] [--strategy NAME] [--max-outer N]" in r.stdout
+    assert "Available strategies: centralized, sequential, linesearch, trustregion" in r.stdout
+
+
+@pytest.mark.parametrize("args,msg", [(["--solver", "nope"], "Unknown solver 'nope'."),
+                                      (["--strategy", "nope"], "Unknown strategy 'nope'."),
+                                      (["--agents", "x"], "Invalid value for --agents: 'x'"),
+                                      (["--bogus"], "Unknown argument '--bogus'"),
+                                      (["--agents"], "Missing value for option '--agents'")])
+def test_cli_errors_match_the_reference(exe_dir, args, msg):
+    # examples/multi_agent_single_track.cpp:145-150: "Error: <what>" on stderr, exit code 1
+    r = _run(exe_dir, "multi_agent_single_track", *args)
+    assert r.returncode == 1
+    assert r.stderr.startswith("Error: " + msg)
+    assert "Use --help to see available options." in r.stderr
+
+
+def test_no_gpu_is_a_loud_error_not_a_cpu_fallback(exe_dir, product_lib):
+    if product_lib.mas_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = _run(exe_dir, "multi_agent_single_track", "--agents", "2", "--strategy", "sequential")
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def _result_line(stdout):
+    m = re.match(r"solver=(\S+) (?:strategy=(\S+) agents=(\d+) )?cost=(\S+) time_ms=(\S+)", stdout.splitlines()[0])
+    assert m, stdout[:200]
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", ["centralized", "sequential", "linesearch", "trustregion", "sequential_nash", "Centralised"])
+def test_single_track_example_matches_oracle(exe_dir, oracle, strategy):
+    # reference defaults: T=10 hard-coded, max_iterations 100, tolerance 1e-5, max_outer 10
+    r = _run(exe_dir, "multi_agent_single_track", "--agents", "6", "--strategy", strategy)
+    assert r.returncode == 0, r.stderr
+    m = _result_line(r.stdout)
+    canon = {"sequential_nash": "sequential", "Centralised": "centralized"}.get(strategy, strategy)
+    assert m.group(1) == "ilqr" and m.group(2) == canon and m.group(3) == "6"
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(6), None, 10, 0.5, strategy=canon)
+    assert m.group(4) == f"{o['total_cost']:.6f}"
+    # trajectory tables: agent_<id>_states / _controls with time,x0.. header (example_utils.hpp:123-167)
+    assert "agent_0_states\ntime,x0,x1,x2,x3\n" in r.stdout and "agent_5_controls\ntime,u0,u1\n" in r.stdout
+
+
+@pytest.mark.gpu
+def test_single_track_example_horizon_100(exe_dir, oracle):
+    r = _run(exe_dir, "multi_agent_single_track", "--agents=8", "--strategy=sequential", "--horizon", "100", "--quiet")
+    assert r.returncode == 0, r.stderr
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(8), None, 100, 0.5, strategy="sequential")
+    assert _result_line(r.stdout).group(4) == f"{o['total_cost']:.6f}"
+
+
+@pytest.mark.gpu
+def test_lqr_and_pendulum_examples(exe_dir, oracle):
+    r = _run(exe_dir, "multi_agent_lqr", "3", "--strategy", "sequential", "--horizon", "50", "--quiet")
+    assert r.returncode == 0, r.stderr
+    o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, oracle.lqr_x0(3), None, 50, 0.1, strategy="sequential")
+    assert _result_line(r.stdout).group(4) == f"{o['total_cost']:.6f}"
+    r = _run(exe_dir, "pendulum_swing_up", "--horizon", "50")
+    assert r.returncode == 0, r.stderr
+    x0, U0 = oracle.pendulum_problem(50, 0.05)
+    o = oracle.solve_batch(oracle.MODEL_PENDULUM, x0, U0, 50, 0.05, strategy="single", max_iterations=1000, tolerance=1e-4)
+    assert _result_line(r.stdout).group(4) == f"{o['cost'][0]:.6f}"
+    assert "pendulum_states\ntime,x0,x1\n" in r.stdout
