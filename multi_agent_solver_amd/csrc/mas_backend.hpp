@@ -85,7 +85,7 @@ struct Backend {
   // one cooperating group of `n` lanes that needs block-wide reductions: emulated serially by
   // the body itself (see CentralBackwardBody)
   template <class F>
-  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0) {
+  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0, size_t = 0) {
     auto t0 = std::chrono::steady_clock::now();
     f.run_serial(n);
     account(name, t0, alg_bytes);
@@ -213,6 +213,12 @@ struct Backend {
     hipExtLaunchKernelGGL(kernel, grid, block, 0, cur, ev0, ev1, 0, args...);
     MAS_HIP_CHECK(hipGetLastError());
   }
+  template <class K, class... Args>
+  void launch_kernel_lds(K kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args) {
+    if (lds_bytes > 64 * 1024) MAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    hipExtLaunchKernelGGL(kernel, grid, block, static_cast<uint32_t>(lds_bytes), cur, ev0, ev1, 0, args...);
+    MAS_HIP_CHECK(hipGetLastError());
+  }
   void resolve_profile() {
     if (pending.empty()) return;
     MAS_HIP_CHECK(hipDeviceSynchronize());
@@ -245,13 +251,13 @@ struct Backend {
     end();
   }
   template <class F>
-  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0) {
+  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0, size_t lds_bytes = 0) {
     if (n <= 0) return;
     begin(name, alg_bytes);
     const int threads = ((n + 63) / 64) * 64;
-    if (threads <= 256) launch_kernel(mas_kernel_group<F, 256>, dim3(1), dim3(threads), f, n);
-    else if (threads <= 512) launch_kernel(mas_kernel_group<F, 512>, dim3(1), dim3(threads), f, n);
-    else launch_kernel(mas_kernel_group<F, 1024>, dim3(1), dim3(threads), f, n);
+    if (threads <= 256) launch_kernel_lds(mas_kernel_group<F, 256>, dim3(1), dim3(threads), lds_bytes, f, n);
+    else if (threads <= 512) launch_kernel_lds(mas_kernel_group<F, 512>, dim3(1), dim3(threads), lds_bytes, f, n);
+    else launch_kernel_lds(mas_kernel_group<F, 1024>, dim3(1), dim3(threads), lds_bytes, f, n);
     end();
   }
 };

@@ -27,6 +27,10 @@ struct Dims {
 
 // (uniform row pointer)[lane index]: lets the compiler address with a scalar base + 32-bit lane offset
 #define MAS_AT(base, row, a) ((base) + static_cast<size_t>(row) * d.Np)[static_cast<unsigned>(a)]
+// uniform (scalar) base pointer + 32-bit per-lane byte offset: the addressing form gfx950 executes with
+// no vector address arithmetic (global_load/store v, v_off32, s[base])
+MAS_HD double ld_off(const double* base, unsigned byte_off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); }
+MAS_HD void st_off(double* base, unsigned byte_off, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 // derivative tiles: one contiguous block of ND doubles per (time step, agent) -- "array of tiles",
 // D[t][agent][ND].  The sweep produces a tile per lane and stages it through LDS so the stores are
 // contiguous; the backward pass consumes 4 consecutive tiles per wavefront as one linear copy.
@@ -145,25 +149,34 @@ struct ForwardBody {
     double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
     double* Uj = Us + static_cast<size_t>(j) * d.T * NU * d.Np;
     double x[NX], xn[NX], u[NU];
+    // addressing: per step one uniform base pointer per array (advanced with scalar adds) plus loop-invariant
+    // 32-bit byte offsets (row_in_step * Np + agent) * 8 per lane
+    constexpr int NR = NU * NX;                                      // the widest per-step block (gain matrix rows)
+    unsigned off[NR];
+    MAS_UNROLL for (int i = 0; i < NR; ++i) off[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+    const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np, sK = static_cast<size_t>(NU) * NX * d.Np;
+    const double *Xt = X, *Ut = U, *kt = kff, *Kt = Kfb;
+    double *Xjt = Xj, *Ujt = Uj;
     // reference point and gains of step t+1 are requested before step t is integrated (software pipeline)
     double xr[NX], ur[NU], k[NU], K[NU * NX], xr_n[NX], ur_n[NU], k_n[NU], K_n[NU * NX];
-    MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(Xj, i, a) = x[i]; }
-    MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = MAS_AT(X, i, a);
-    MAS_UNROLL for (int i = 0; i < NU; ++i) ur[i] = MAS_AT(U, i, a);
-    MAS_UNROLL for (int i = 0; i < NU; ++i) k[i] = MAS_AT(kff, i, a);
-    MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = MAS_AT(Kfb, i, a);
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = ld_off(x0, off[i]); st_off(Xjt, off[i], x[i]); }
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = ld_off(Xt, off[i]);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) ur[i] = ld_off(Ut, off[i]);
+    MAS_UNROLL for (int i = 0; i < NU; ++i) k[i] = ld_off(kt, off[i]);
+    MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = ld_off(Kt, off[i]);
     double c = 0.0;
     for (int t = 0; t < d.T; ++t) {
-      const int tn = t + 1 < d.T ? t + 1 : t;
-      MAS_UNROLL for (int i = 0; i < NX; ++i) xr_n[i] = MAS_AT(X, tn * NX + i, a);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) ur_n[i] = MAS_AT(U, tn * NU + i, a);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) k_n[i] = MAS_AT(kff, tn * NU + i, a);
-      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K_n[i] = MAS_AT(Kfb, tn * NU * NX + i, a);
+      if (t + 1 < d.T) { Xt += sX; Ut += sU; kt += sU; Kt += sK; }   // uniform
+      MAS_UNROLL for (int i = 0; i < NX; ++i) xr_n[i] = ld_off(Xt, off[i]);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) ur_n[i] = ld_off(Ut, off[i]);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) k_n[i] = ld_off(kt, off[i]);
+      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K_n[i] = ld_off(Kt, off[i]);
       forward_control<M>(x, xr, ur, k, K, alpha, clamp, lb, ub, u);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(Uj, t * NU + i, a) = u[i];
+      MAS_UNROLL for (int i = 0; i < NU; ++i) st_off(Ujt, off[i], u[i]);
       c += M::stage_cost(x, u, t, P);
       rk4_step<M>(x, u, dt, xn, P);
-      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(Xj, (t + 1) * NX + i, a) = x[i]; }
+      Xjt += sX; Ujt += sU;
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; st_off(Xjt, off[i], x[i]); }
       MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = xr_n[i];
       MAS_UNROLL for (int i = 0; i < NU; ++i) { ur[i] = ur_n[i]; k[i] = k_n[i]; }
       MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = K_n[i];

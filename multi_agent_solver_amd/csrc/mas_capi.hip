@@ -151,6 +151,7 @@ int mas_hip_get_kernel_times(mas_hip_solver* h, mas_hip_kernel_time* out, int ca
   if (!count) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) {
     s.be.resolve_profile();
+    s.fold_kernel_stamps();
     int n = 0;
     for (const auto& kv : s.be.stats) {
       if (out && n < capacity) {

@@ -24,10 +24,20 @@ namespace mas {
 // ------------------------------------------------------------------------- sweep --------
 template <class M>
 __global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ U,
-                                                        double* __restrict__ D, const int* __restrict__ active, int lo, int n) {
+                                                        double* __restrict__ D, const int* __restrict__ active, int lo, int n,
+                                                        unsigned long long* __restrict__ stamp) {
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
   constexpr int CH = 16;              // tile elements staged per pass
+  // profiling only (stamp == nullptr otherwise): every workgroup stores its first and last 100-MHz REFCLK
+  // tick in its own slot (no atomics, no contention); the host takes min / max = the kernel's execution
+  // span, free of the dispatch overhead that host-side events include
+  unsigned long long* my_stamp = stamp ? stamp + 2 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
+  if (my_stamp && threadIdx.x == 0 && threadIdx.y == 0) my_stamp[0] = __builtin_amdgcn_s_memrealtime();
+  struct StampEnd {
+    unsigned long long* p;
+    __device__ ~StampEnd() { if (p && threadIdx.x == 0 && threadIdx.y == 0) p[1] = __builtin_amdgcn_s_memrealtime(); }
+  } stamp_end{my_stamp};
   constexpr int PITCH = CH + 1;       // odd pitch: the 16 lanes of a ds_write_b64 group hit distinct banks
   __shared__ double stage[4][64 * PITCH];
 
@@ -73,7 +83,7 @@ struct BackwardTileLayout {
   using L = DerivLayout<M>;
   static constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
   static constexpr int oD = 0, oV = oD + ND, oVx = oV + NX * NX, oAtV = oVx + NX, oBtV = oAtV + NX * NX, oQx = oBtV + NU * NX,
-                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, kEnd = oQuu + NU * NU;
+                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oDummy = oQuu + NU * NU, kEnd = oDummy + 1;
   static constexpr int STRIDE = (kEnd % 32 == 0) ? kEnd + 2 : kEnd;     // keep agents on different LDS banks
 };
 
@@ -102,10 +112,8 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   if (__ballot(valid) == 0ull) return;              // uniform for the (single-wave) block
   double* T = lds + slot * TL::STRIDE;
 
-  if (!valid) {                                     // idle slot: benign operands so its lanes leave the ladder at once
+  if (!valid) {                                     // idle slot: finite operands (its lanes run the same code, results unused)
     for (int e = lane; e < TL::STRIDE; e += LPA) T[e] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < NU) T[TL::oQuu + lane * NU + lane] = 1.0;
   }
   if (valid && lane == 0) {                         // terminal boundary condition, ilqr.hpp:92-102
     double xT[NX], vx[NX], vxx[NX * NX];
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   int p1[R1], q1[R1], b1[R1], o1[R1];              // pass 1: out = [bias +] sum_k T[p+k] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R1; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, qa = 0, ba = -1, oa = -1;
+    int pa = 0, qa = 0, ba = -1, oa = TL::oDummy;
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
     else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
     else if (w < NX * NX + NU * NX + NX) { const int i = w - NX * NX - NU * NX; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   int p2[R2], ps2[R2], q2[R2], b2[R2], o2[R2];     // pass 2: out = bias + sum_k T[p + k*ps] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R2; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, ps = 1, qa = 0, ba = 0, oa = -1;
+    int pa = 0, ps = 1, qa = 0, ba = 0, oa = TL::oDummy;
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oAtV + i; ps = NX; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLxx + w; oa = TL::oQxx + w; }
     else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLux + e; oa = TL::oQux + e; }
     else if (w < W2) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
@@ -146,8 +154,18 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   };
   fetch(d.T - 1);
   long long regs = 0;
+  // gain stores: uniform per-step base pointers + loop-invariant 32-bit byte offsets (row * Np + agent) * 8
+  constexpr int RMX = (NX * NX + LPA - 1) / LPA;
+  unsigned goff[NU], koff[RMX][NU];                  // k rows; this lane's gain column (rows i*NU + m) per round
+  MAS_UNROLL for (int m = 0; m < NU; ++m) goff[m] = static_cast<unsigned>((static_cast<size_t>(m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int r = 0; r < RMX; ++r) {
+    const int w = lane + r * LPA, i = (w < NX * NX) ? (w % NX) : 0;
+    MAS_UNROLL for (int m = 0; m < NU; ++m) koff[r][m] = static_cast<unsigned>((static_cast<size_t>(i * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  }
+  double* kff_t = kff + static_cast<size_t>(d.T - 1) * NU * d.Np;
+  double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
 
-  for (int t = d.T - 1; t >= 0; --t) {
+  for (int t = d.T - 1; t >= 0; --t, kff_t -= static_cast<size_t>(NU) * d.Np, Kfb_t -= static_cast<size_t>(NU) * NX * d.Np) {
     MAS_UNROLL for (int r = 0; r < NREG; ++r) {
       const int idx = r * 64 + tid;
       if (idx < CNT) { const int s = idx / ND; lds[s * TL::STRIDE + TL::oD + (idx - s * ND)] = pre[r]; }
@@ -164,7 +182,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         const double bias = T[b1[r] < 0 ? 0 : b1[r]];
         res[r] = (b1[r] < 0) ? s : bias + s;
       }
-      MAS_UNROLL for (int r = 0; r < R1; ++r) { if (valid && o1[r] >= 0) T[o1[r]] = res[r]; }
+      MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // padding items write the tile's dummy slot
     }
     __syncthreads();
     // ---- pass 2 (second factors of ilqr.hpp:117-119)
@@ -175,7 +193,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p2[r] + k * ps2[r]] * T[q2[r] + k];
         res[r] = T[b2[r]] + s;
       }
-      MAS_UNROLL for (int r = 0; r < R2; ++r) { if (valid && o2[r] >= 0) T[o2[r]] = res[r]; }
+      MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
     }
     __syncthreads();
     // ---- pass 3 (ilqr.hpp:172-192)
@@ -191,8 +209,15 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       {
         double cur[NU * NU];
         MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = quu[i];
+        // reg_q = 1e-6 * 10^q by repeated multiplication, exactly the reference's `reg *= 10.0`; the
+        // additions stay sequential (floating-point addition is not associative) but are predicated
+        // straight-line code, no loop: lane r applies the first r of them
         double reg = 1e-6;
-        for (int q = 0; q < lane; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; reg *= 10.0; }
+        MAS_UNROLL for (int q = 0; q < LPA - 1; ++q) {
+          if (q < lane) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; }
+          reg *= 10.0;
+        }
+        double reg_next = 0.0;                                         // this lane's next rung value, only needed past rung 15
         int base = 0, win = -1;
         for (;;) {
           MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
@@ -203,7 +228,8 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
           if (win < 0 && base + LPA > kRegLadderMax) win = base + LPA - 1;     // guard, never reached (see kRegLadderMax)
           if (__ballot(win < 0) == 0ull) break;                                // every agent of the wavefront is settled
           if (win < 0) {                                                      // this agent goes on with rungs base+16 .. base+31
-            for (int q = 0; q < LPA; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; reg *= 10.0; }
+            if (base == 0) { reg_next = 1e-6; for (int q = 0; q < lane; ++q) reg_next *= 10.0; }
+            for (int q = 0; q < LPA; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
             base += LPA;
           }
         }
@@ -219,7 +245,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int q = 0; q < NU; ++q) s += ninv[q * NU + m] * qu[q];
         kf[m] = s;
       }
-      if (valid && lane == 0) { MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_AT(kff, t * NU + m, a) = kf[m]; }
+      if (valid && lane == 0) { MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]); }
 
       constexpr int RM = (NX * NX + LPA - 1) / LPA;                  // rounds over the v_xx entries
       MAS_UNROLL for (int r = 0; r < RM; ++r) {
@@ -257,10 +283,9 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: a lower or diagonal
         // entry averages the old values, an upper entry sees its (already rewritten) mirror
         const double sym = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));
-        if (live) T[TL::oV + w] = sym;
+        T[live ? (TL::oV + w) : TL::oDummy] = sym;
         // the lanes of the first tile column (j == 0) also own gain column i and v_x entry i, :186,188-189
-        if (live && j == 0) {
-          MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_AT(Kfb, t * NU * NX + i * NU + m, a) = Ki[m];
+        {
           double vxi;
           s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * qu[m];
           vxi = qx_i + s;
@@ -268,7 +293,9 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
           vxi = vxi + s;
           s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
           vxi = vxi + s;
-          T[TL::oVx + i] = vxi;
+          const bool owner = live && j == 0;
+          T[owner ? (TL::oVx + i) : TL::oDummy] = vxi;
+          if (owner) { MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[r][m], Ki[m]); }
         }
       }
     }

@@ -56,6 +56,7 @@ class SolverBase {
   virtual void get_trust_radii(double* radii) = 0;
   virtual void debug_backward(double* derivs, double* k, double* K, int64_t* regs) = 0;
   virtual HostStats get_stats() = 0;
+  virtual void fold_kernel_stamps() {}
   virtual void reset_stats() = 0;
 
   // iLQR::set_params, ilqr.hpp:39-55
@@ -227,7 +228,12 @@ class SolverImpl final : public SolverBase {
       const double nact = static_cast<double>(d.N);
       stats.agent_iterations += d.N;
       launch_sweep(sweep_bytes() * nact);
-      be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events}, d.N, backward_bytes() * nact);
+      {
+        const size_t lds_bytes = static_cast<size_t>((d.N + 63) / 64 * 64) * L::ND * sizeof(double);
+        const bool staged = lds_bytes <= 150 * 1024;      // 160 KB of LDS per CU
+        be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, staged ? 1 : 0}, d.N, backward_bytes() * nact,
+                        staged ? lds_bytes : 0);
+      }
       be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
@@ -272,8 +278,28 @@ class SolverImpl final : public SolverBase {
     for (auto v : rg) s.reg_events += v;
     return s;
   }
+  // in-kernel timing of the sweep -> kernel statistics entry "sweep_inkernel" (100-MHz REFCLK ticks)
+  void fold_kernel_stamps() override {
+#if !defined(MAS_HOST_EMULATION)
+    if (!sweep_stamps || stamp_launches.empty()) return;
+    be.sync();
+    std::vector<unsigned long long> h(stamp_used);
+    be.d2h(h.data(), sweep_stamps, sizeof(unsigned long long) * stamp_used);
+    KernelStat& ks = be.stats["sweep_inkernel"];
+    for (const auto& sl : stamp_launches) {
+      unsigned long long lo_t = ~0ull, hi_t = 0ull;
+      for (size_t b = 0; b < sl.count; b += 2) {
+        if (h[sl.off + b] == 0ull) continue;                       // workgroup never ran (cannot happen) or slot unused
+        lo_t = std::min(lo_t, h[sl.off + b]); hi_t = std::max(hi_t, h[sl.off + b + 1]);
+      }
+      if (hi_t == 0ull) continue;
+      ks.launches++; ks.total_ms += static_cast<double>(hi_t - lo_t) * 1e-5; ks.algorithmic_bytes += sl.bytes;
+    }
+    stamp_used = 0; stamp_launches.clear();
+#endif
+  }
   void reset_stats() override {
-    stats = HostStats{}; reg_base = 0;
+    stats = HostStats{}; reg_base = 0; stamp_used = 0; stamp_launches.clear();
     be.zero(reg_events, sizeof(long long) * d.Np);
   }
 
@@ -315,7 +341,19 @@ class SolverImpl final : public SolverBase {
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
 #else
     be.begin("sweep", bytes);
-    be.launch_kernel(mas_sweep_kernel<M>, dim3((hi - lo + 63) / 64, (d.T + 3) / 4), dim3(64, 4), d, P, X, U, D, active, lo, hi);
+    unsigned long long* stamp = nullptr;
+    const dim3 grid((hi - lo + 63) / 64, (d.T + 3) / 4);
+    if (be.profiling) {                                   // in-kernel REFCLK stamps for the roofline kernel
+      const size_t per_launch = 2 * static_cast<size_t>(grid.x) * grid.y;
+      if (!sweep_stamps) { stamp_capacity = per_launch * kMaxStampedLaunches; sweep_stamps = static_cast<unsigned long long*>(be.alloc(sizeof(unsigned long long) * stamp_capacity)); }
+      if (stamp_used + per_launch <= stamp_capacity) {
+        stamp = sweep_stamps + stamp_used;
+        MAS_HIP_CHECK(hipMemsetAsync(stamp, 0, sizeof(unsigned long long) * per_launch, be.cur));
+        stamp_launches.push_back({stamp_used, per_launch, bytes});
+        stamp_used += per_launch;
+      }
+    }
+    be.launch_kernel(mas_sweep_kernel<M>, grid, dim3(64, 4), d, P, X, U, D, active, lo, hi, stamp);
     be.end();
 #endif
   }
@@ -443,6 +481,11 @@ class SolverImpl final : public SolverBase {
   bool have_x0 = false, initialized = false, saved = false, last_total_valid = false, rollout_consistent = false;
   double central_total = 0.0;
   long long reg_base = 0;
+  static constexpr int kMaxStampedLaunches = 1024;
+  struct StampedLaunch { size_t off, count; double bytes; };
+  unsigned long long* sweep_stamps = nullptr;
+  size_t stamp_capacity = 0, stamp_used = 0;
+  std::vector<StampedLaunch> stamp_launches;
   std::vector<SubBatch> subs;
   HostStats stats;
 };
