@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--agents-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -143,13 +144,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: multi_agent_solver_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()      # one rank per GPU (several per GPU only in the gloo rehearsal)
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.backend)
 
     def sync():
         torch.cuda.synchronize()
@@ -160,12 +165,14 @@ def main():
 
     w = dict(WORKLOADS[args.workload])
     per_gpu = args.agents_per_gpu or w["agents"]
+    if per_gpu != w["agents"]:
+        w["name"] = w["name"].replace(f"{w['agents']} agents", f"{per_gpu} agents") + " [agent count overridden]"
     n_total = per_gpu * world
     lo, hi = shard_range(n_total, world, rank)
 
-    elapsed, st, kt, _ = measure(w, hi - lo, lo, n_total, local_rank, args.steps, args.warmup, sync, barrier)
+    elapsed, st, kt, _ = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier)
     vals = torch.tensor([elapsed, float(st["agent_iterations"]), float(st["converged_solves"]), float(st["solves"])],
-                        dtype=torch.float64, device="cuda")
+                        dtype=torch.float64, device=("cuda" if args.backend == "nccl" else "cpu"))
     if dist is not None:
         tmax = vals[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = vals[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -200,7 +207,7 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not args.no_also and args.workload == "c3":
             w2 = dict(WORKLOADS["c2"])
-            el2, st2, kt2, _ = measure(w2, w2["agents"], 0, w2["agents"], local_rank, max(3, args.steps), 1, sync, barrier)
+            el2, st2, kt2, _ = measure(w2, w2["agents"], 0, w2["agents"], device, max(3, args.steps), 1, sync, barrier)
             out["also_config2"] = {"workload": w2["name"], "value": st2["agent_iterations"] / el2, "unit": "agent-iterations/s",
                                    "ms_per_step": 1e3 * el2 / max(3, args.steps), "roofline": roofline_of(kt2, "sweep")}
         print(json.dumps(out))

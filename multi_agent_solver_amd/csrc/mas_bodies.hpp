@@ -328,6 +328,14 @@ struct AosToSoaBody {
     for (int r = 0; r < rows; ++r) MAS_AT(soa, c * rows + r, a) = aos[(static_cast<size_t>(a) * cols + c) * rows + r];
   }
 };
+// derivative tiles [T][Np][ND] -> agent-fastest rows [T*ND][Np] (centralised backward pass: one lane per agent)
+struct TilesToSoaBody {
+  Dims d; int nd;
+  const double* tiles; double* soa;
+  MAS_HD void operator()(int a, int t) const {
+    for (int e = 0; e < nd; ++e) MAS_AT(soa, t * nd + e, a) = MAS_TILE_AT(tiles, nd, t, a, e);
+  }
+};
 // derivative tiles [T][Np][ND] -> host layout [N][T][ND] (parity tests only)
 struct TilesToHostBody {
   Dims d; int nd;

@@ -51,7 +51,7 @@ struct CentralBackwardBody {
   Dims d; ModelParams P;
   const double* X; const double* D;
   double* kff; double* Kfb; long long* reg_events;
-  int use_lds;
+  const double* Dsoa;      // [T*ND][Np] agent-fastest copy of the tiles (GPU path); the emulation reads the tiles
 
   struct AgentState { double vx[M::NX], vxx[M::NX * M::NX]; };
 
@@ -98,35 +98,28 @@ struct CentralBackwardBody {
     reg_events[0] += regs;
   }
 #else
-  // The derivative tiles of one time step (blockDim x ND doubles, contiguous in HBM) are copied into LDS
-  // with coalesced loads -- each lane then reads its own tile from LDS; reading the tile array directly
-  // with one lane per agent would touch a different cache line per lane and load.  `tiles_lds` is the
-  // dynamic-LDS buffer (nullptr: too many agents for 160 KB, fall back to direct reads).
+  // One lane per agent; the derivative rows are read from an agent-fastest (SoA) copy of the tiles
+  // (Dsoa, made by TilesToSoaBody) so that the 64 lanes of a wavefront load 64 consecutive doubles,
+  // and the rows of step t-1 are requested while step t is being computed.
   __device__ void run_block(int n) const {
     using L = DerivLayout<M>;
     constexpr int NU = M::NU, ND = L::ND;
-    extern __shared__ double tiles_lds[];
-    const bool staged = use_lds != 0;
     const int a = threadIdx.x;
     const bool valid = a < n;
     AgentState s; QFunction<M> q;
     if (valid) begin(a, s);
     long long regs = 0;
-    const int total = static_cast<int>(blockDim.x) * ND;
+    double Dl[ND], Dn[ND];
+    if (valid) { MAS_UNROLL for (int i = 0; i < ND; ++i) Dl[i] = MAS_AT(Dsoa, (d.T - 1) * ND + i, a); }
     for (int t = d.T - 1; t >= 0; --t) {
       double cur[NU * NU], Lf[NU * NU];
-      if (staged) {
-        const double* src = D + static_cast<size_t>(t) * d.Np * ND;
-        __syncthreads();                                   // previous step's tile reads are done
-        for (int idx = a; idx < total; idx += blockDim.x) tiles_lds[idx] = src[idx];
-        __syncthreads();
-        if (valid) {
-          double Dl[ND];
-          MAS_UNROLL for (int i = 0; i < ND; ++i) Dl[i] = tiles_lds[a * ND + i];
-          assemble_q<M>(Dl, s.vx, s.vxx, q);
-          MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = q.quu[i];
-        }
-      } else if (valid) { assemble(a, t, s, q); MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = q.quu[i]; }
+      if (valid) {
+        const int tn = t > 0 ? t - 1 : 0;
+        MAS_UNROLL for (int i = 0; i < ND; ++i) Dn[i] = MAS_AT(Dsoa, tn * ND + i, a);
+        assemble_q<M>(Dl, s.vx, s.vxx, q);
+        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = q.quu[i];
+        MAS_UNROLL for (int i = 0; i < ND; ++i) Dl[i] = Dn[i];
+      }
       double reg = 1e-6; int rungs = 0;
       for (;;) {                                        // every thread of the block takes the same trips
         int fail = 0;

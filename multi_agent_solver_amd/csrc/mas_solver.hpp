@@ -228,12 +228,9 @@ class SolverImpl final : public SolverBase {
       const double nact = static_cast<double>(d.N);
       stats.agent_iterations += d.N;
       launch_sweep(sweep_bytes() * nact);
-      {
-        const size_t lds_bytes = static_cast<size_t>((d.N + 63) / 64 * 64) * L::ND * sizeof(double);
-        const bool staged = lds_bytes <= 150 * 1024;      // 160 KB of LDS per CU
-        be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, staged ? 1 : 0}, d.N, backward_bytes() * nact,
-                        staged ? lds_bytes : 0);
-      }
+      if (!Dsoa) Dsoa = dalloc(static_cast<size_t>(d.T) * L::ND * d.Np);
+      be.template launch_2d<4>("tiles_to_soa", TilesToSoaBody{d, L::ND, D, Dsoa}, d.N, d.T);
+      be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, Dsoa}, d.N, backward_bytes() * nact);
       be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
@@ -473,6 +470,7 @@ class SolverImpl final : public SolverBase {
   Dims d{}; double dt = 0.0; ModelParams P{}; bool clamp = false; double lb[NU], ub[NU];
   double *x0 = nullptr, *X = nullptr, *U = nullptr, *D = nullptr, *kff = nullptr, *Kfb = nullptr, *Xs = nullptr, *Us = nullptr;
   double *trial_merit = nullptr, *cost = nullptr, *merit = nullptr, *x0_saved = nullptr, *U_saved = nullptr, *stage = nullptr;
+  double *Dsoa = nullptr;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
