@@ -5,7 +5,7 @@
 // rows lives at base[r * Np + a], Np = N rounded up to a multiple of 64.  A wavefront's 64 lanes
 // are 64 consecutive agents, so each load/store instruction touches 64 consecutive doubles (512 B,
 // fully coalesced).  Rows are (t, component) pairs, t-major.  The linearisation output is the
-// exception: it is an array of per-(t, agent) tiles (MAS_TILE_AT below).
+// exception: it is an array of per-(t, agent) tiles in a chunk-major block layout (tile_offset below).
 //
 // Each body is a functor called with (agent) or (agent, y); y is a time step (linearisation
 // sweep, commit) or an alpha-trial index (speculative line search).
@@ -31,10 +31,20 @@ struct Dims {
 // no vector address arithmetic (global_load/store v, v_off32, s[base])
 MAS_HD double ld_off(const double* base, unsigned byte_off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); }
 MAS_HD void st_off(double* base, unsigned byte_off, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off) = v; }
-// derivative tiles: one contiguous block of ND doubles per (time step, agent) -- "array of tiles",
-// D[t][agent][ND].  The sweep produces a tile per lane and stages it through LDS so the stores are
-// contiguous; the backward pass consumes 4 consecutive tiles per wavefront as one linear copy.
-#define MAS_TILE_AT(base, ND_, t, a, e) (base)[(static_cast<size_t>(t) * d.Np + static_cast<size_t>(a)) * (ND_) + (e)]
+// Derivative tiles D(t, agent) = ND doubles (A,B,l_x,l_u,l_xx,l_uu,l_ux).  Storage is chunk-major
+// inside blocks of 64 agents:
+//     D[t][agent/64][chunk c][agent%64][e%16],   chunk c = e/16, chunk width cw_c = min(16, ND - 16c)
+// i.e. element e of tile (t,a) sits at  ((t*Np/64 + a/64)*64*ND) + c*16*64 + (a%64)*cw_c + e%16.
+//  * the sweep (a wavefront = 64 agents of one step) stages 16 elements per lane through LDS and writes
+//    each chunk as ONE contiguous, 64-byte-aligned run of 64*cw_c doubles (8 KiB): full-line stores only;
+//  * the backward pass (a wavefront = 4 consecutive agents) reads 4*cw_c contiguous doubles per chunk.
+constexpr int kTileChunk = 16;
+MAS_HD size_t tile_offset(int nd, size_t Np, int t, int a, int e) {
+  const int c = e / kTileChunk, cw = (nd - c * kTileChunk < kTileChunk) ? (nd - c * kTileChunk) : kTileChunk;
+  return (static_cast<size_t>(t) * (Np / 64) + static_cast<size_t>(a / 64)) * 64 * nd + static_cast<size_t>(c) * kTileChunk * 64 +
+         static_cast<size_t>(a % 64) * cw + static_cast<size_t>(e % kTileChunk);
+}
+#define MAS_TILE_AT(base, ND_, t, a, e) (base)[tile_offset((ND_), d.Np, (t), (a), (e))]
 
 // -------------------------------------------------------------------------------------------
 // integrate_horizon + objective (ilqr.hpp:75-78; ocp.hpp:110,182): one lane per agent.
@@ -73,7 +83,7 @@ template <class M>
 struct SweepBody {
   Dims d; ModelParams P;
   const double* X; const double* U;
-  double* D;             // [T][Np][ND] tiles
+  double* D;             // derivative tiles (tile_offset)
   const int* active;
   MAS_HD void operator()(int a, int t) const {
     using L = DerivLayout<M>;

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, c
   __shared__ double stage[4][64 * PITCH];
 
   const int lane = threadIdx.x, w = threadIdx.y;
-  const int a0 = lo + blockIdx.x * 64, a = a0 + lane;       // lo is a multiple of 64
+  const int a0 = lo + blockIdx.x * 64, a = a0 + lane;       // lo is a multiple of 64, so a0 starts a 64-agent block
   const int t = blockIdx.y * 4 + w;
   if (t >= d.T) return;                                    // wave-uniform
   const bool act = (a < n) && active[a] != 0;
@@ -60,18 +60,21 @@ __global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, c
   }
 
   double* st = stage[w];
-  double* tiles = D + (static_cast<size_t>(t) * d.Np + a0) * ND;   // 64 consecutive tiles
+  // the 64 tiles of this wavefront: 4 (5, 7 ...) chunk runs of 64*cw doubles each, contiguous and 64-B aligned
+  double* block = D + (static_cast<size_t>(t) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
+  const bool full = mask == ~0ull;                                  // wave-uniform
   MAS_UNROLL for (int c0 = 0; c0 < ND; c0 += CH) {
-    constexpr int dummy = 0; (void)dummy;
     const int cw = (ND - c0 < CH) ? (ND - c0) : CH;                // compile-time after unrolling
+    double* run = block + static_cast<size_t>(c0) * 64;
     __builtin_amdgcn_wave_barrier();
     MAS_UNROLL for (int e = 0; e < CH; ++e) { if (e < cw) st[lane * PITCH + e] = Dl[c0 + e]; }
     __builtin_amdgcn_wave_barrier();                                // LDS ops of one wave complete in order
     MAS_UNROLL for (int k = 0; k < CH; ++k) {
       if (k < cw) {
-        const int idx = k * 64 + lane;                              // linear index into the 64 x cw chunk
+        const int idx = k * 64 + lane;                              // linear index into the run: [agent][cw]
         const int ag = idx / cw, e = idx - ag * cw;
-        if ((mask >> ag) & 1ull) tiles[static_cast<size_t>(ag) * ND + c0 + e] = st[ag * PITCH + e];
+        const double v = st[ag * PITCH + e];
+        if (full || ((mask >> ag) & 1ull)) run[idx] = v;            // 64 lanes -> 512 contiguous bytes
       }
     }
   }
@@ -103,7 +106,6 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
   constexpr int APW = 4, LPA = 16;                  // agents per wavefront, lanes per agent
-  constexpr int CNT = APW * ND, NREG = (CNT + 63) / 64;
   __shared__ double lds[APW * TL::STRIDE];
 
   const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid >> 4;
@@ -146,11 +148,17 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
     p2[r] = pa; ps2[r] = ps; q2[r] = qa; b2[r] = ba; o2[r] = oa;
   }
 
-  // software pipeline: the four tiles of step t-1 travel HBM -> registers while step t is computed
-  double pre[NREG];
+  // software pipeline: the four tiles of step t-1 travel HBM -> registers while step t is computed.
+  // Per chunk the 4 tiles are 4*cw contiguous doubles (tile_offset); lane tid < 4*cw takes one of them.
+  constexpr int NCH = (ND + kTileChunk - 1) / kTileChunk;
+  double pre[NCH];
   auto fetch = [&](int t) {
-    const double* src = D + (static_cast<size_t>(t) * d.Np + a0) * ND;
-    MAS_UNROLL for (int r = 0; r < NREG; ++r) { const int idx = r * 64 + tid; pre[r] = (idx < CNT) ? src[idx] : 0.0; }
+    const double* blockp = D + (static_cast<size_t>(t) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
+    MAS_UNROLL for (int c = 0; c < NCH; ++c) {
+      const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
+      const double* run = blockp + static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a0 % 64) * cw;
+      pre[c] = (tid < APW * cw) ? run[tid] : 0.0;
+    }
   };
   fetch(d.T - 1);
   long long regs = 0;
@@ -166,9 +174,9 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
 
   for (int t = d.T - 1; t >= 0; --t, kff_t -= static_cast<size_t>(NU) * d.Np, Kfb_t -= static_cast<size_t>(NU) * NX * d.Np) {
-    MAS_UNROLL for (int r = 0; r < NREG; ++r) {
-      const int idx = r * 64 + tid;
-      if (idx < CNT) { const int s = idx / ND; lds[s * TL::STRIDE + TL::oD + (idx - s * ND)] = pre[r]; }
+    MAS_UNROLL for (int c = 0; c < NCH; ++c) {
+      const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
+      if (tid < APW * cw) { const int sl = tid / cw; lds[sl * TL::STRIDE + TL::oD + c * kTileChunk + (tid - sl * cw)] = pre[c]; }
     }
     if (t > 0) fetch(t - 1);
     __syncthreads();
