@@ -64,6 +64,8 @@ struct Backend {
   void record(Event&) {}
   void wait(Event&) {}
   void d2h_async(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+  size_t mark() const { return 0; }
+  void scale_bytes(size_t, size_t, double) {}
 
   template <int BY, class F>
   void launch_1d(const char* name, const F& f, int n, double alg_bytes = 0.0) { launch_1d_range<BY>(name, f, 0, n, alg_bytes); }
@@ -169,6 +171,10 @@ struct Backend {
   void record(Event& e) { MAS_HIP_CHECK(hipEventRecord(e, cur)); }
   void wait(Event& e) { MAS_HIP_CHECK(hipEventSynchronize(e)); }
   void d2h_async(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, cur)); }
+  // profiling: launches of a round are recorded with per-agent byte counts and scaled once the round's
+  // active-agent count is known (the host runs one round ahead of the device)
+  size_t mark() const { return pending.size(); }
+  void scale_bytes(size_t from, size_t to, double n) { for (size_t i = from; i < to && i < pending.size(); ++i) pending[i].bytes *= n; }
   void destroy() {
     (void)hipSetDevice(device);
     for (auto& p : pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }

@@ -205,7 +205,9 @@ struct SelectBody {
   int* active; int* alpha_sel; int* iters_solve; int* iters_total; int* exit_code;
   int* n_active;              // counter of agents still active after this iteration
   long long* n_converged;
+  long long* clear;           // counter pair of the ring that the round after next will use: reset here
   MAS_HD void operator()(int a) const {
+    if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
     if (!active[a]) { alpha_sel[a] = -1; return; }
     const double cur = merit[a];
     int sel = -1; double best = cur;

@@ -65,7 +65,6 @@ class SolverBase {
     else if (key == "tolerance") { tolerance = value; has_tolerance = true; }
     else if (key == "max_ms") { max_ms = value; has_max_ms = true; }
     else if (key == "debug") { debug = value > 0.5; }
-    else if (key == "sub_batches") { sub_batches = static_cast<int>(value); }   // extension: concurrent agent ranges (0 = auto)
     else return false;   // penalty*, constraint_tolerance, ... and unknown keys: ignored
     return true;
   }
@@ -79,7 +78,6 @@ class SolverBase {
   double max_ms = std::numeric_limits<double>::infinity();
   bool debug = false;
   bool has_max_iterations = false, has_tolerance = false, has_max_ms = false;
-  int sub_batches = 0;
 };
 
 template <class M>
@@ -120,7 +118,7 @@ class SolverImpl final : public SolverBase {
   }
   ~SolverImpl() override {
     try { be.sync(); } catch (...) {}
-    for (auto& sb : subs) { be.drop_stream(sb.st); be.drop_event(sb.ev); }
+    if (round_events_made) for (auto& e : round_ev) be.drop_event(e);
     for (void* p : allocations) be.free(p);
     be.free_pinned(host_counters); be.free_pinned(host_central);
     be.destroy();
@@ -374,35 +372,16 @@ class SolverImpl final : public SolverBase {
     return f;
   }
 
-  // Agent ranges that iterate concurrently.  Every kernel of the iteration is latency-bound at a few
-  // thousand agents (one wavefront per SIMD or less), so independent ranges on separate HIP streams
-  // overlap almost perfectly; the per-agent arithmetic is untouched.  Range bounds are multiples of 64.
-  struct SubBatch { int lo = 0, hi = 0; long long n_active = 0; bool done = false; Stream st{}; typename Backend::Event ev{}; };
-  void ensure_sub_batches() {
-    int want = sub_batches > 0 ? sub_batches : 1;   // measured on MI355X at 4096 agents: 1 is best (the round is latency-bound per agent)
-    const int groups = static_cast<int>(d.Np / 64);
-    if (want > 8) want = 8;
-    if (want > groups) want = groups;
-    if (want < 1) want = 1;
-    if (static_cast<int>(subs.size()) == want) return;
-    be.sync();
-    for (auto& sb : subs) { be.drop_stream(sb.st); be.drop_event(sb.ev); }
-    subs.clear();
-    for (int k = 0; k < want; ++k) {
-      SubBatch sb;
-      sb.lo = static_cast<int>(static_cast<long long>(groups) * k / want) * 64;
-      sb.hi = static_cast<int>(static_cast<long long>(groups) * (k + 1) / want) * 64;
-      if (sb.hi > d.N) sb.hi = d.N;
-      if (sb.lo >= sb.hi) continue;
-      sb.st = be.make_stream(); sb.ev = be.make_event();
-      subs.push_back(sb);
-    }
-  }
-
-  // N x iLQR::solve with per-agent acceptance and termination
+  // N x iLQR::solve with per-agent acceptance and termination.
+  //
+  // One round = sweep -> backward -> forward -> select -> commit (+ a 16-byte read-back of "agents still
+  // active").  On the GPU the host runs ONE ROUND AHEAD: round r+1 is enqueued before the read-back of round
+  // r is awaited, so the device never idles on the host.  If round r turns out to have retired the last
+  // agent, the already-enqueued round finds no active agent and every kernel exits at its first ballot --
+  // results are unaffected.  (Agent ranges on separate streams were also tried: no gain at 4096 agents, the
+  // round is bound by each agent's own sequential chain -- DESIGN.md section 4.)
   void solve_all() {
     ensure_initialized();
-    ensure_sub_batches();
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
     // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78).  After
     // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
@@ -414,46 +393,62 @@ class SolverImpl final : public SolverBase {
     } else {
       be.d2d(merit, cost, sizeof(double) * d.Np);   // current_merit = compute_merit(x,u) == objective (ilqr.hpp:78)
     }
-    be.sync();                                       // fan out: the sub-batch streams start from a settled state
+    be.zero(counters, sizeof(long long) * 2 * kCounterRing);
     stats.solves += d.N;
+    if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
     const auto t0 = std::chrono::steady_clock::now();
-    for (auto& sb : subs) { sb.n_active = sb.hi - sb.lo; sb.done = false; }
     const ForwardBody<M> fwd = make_forward();
-    for (int iter = 0; iter < max_iterations; ++iter) {
-      bool any = false;
-      const bool timeout = timed_out(t0);
-      for (size_t k = 0; k < subs.size(); ++k) {
-        SubBatch& sb = subs[k];
-        if (sb.done) continue;
-        any = true;
-        be.use(sb.st);
-        if (timeout) { be.template launch_1d_range<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, sb.lo, sb.hi); sb.done = true; be.record(sb.ev); continue; }
-        const double nact = static_cast<double>(sb.n_active);
-        stats.agent_iterations += sb.n_active;      // every active agent executes exactly one iLQR iteration per round
-        launch_sweep(sweep_bytes() * nact, sb.lo, sb.hi);
-        launch_backward(backward_bytes() * nact, sb.lo, sb.hi);
-        be.template launch_2d_range<1>("forward", fwd, sb.lo, sb.hi, kNumAlphas, forward_bytes() * nact * kNumAlphas);
-        long long* ctr = counters + 2 * k;
-        be.zero(ctr, sizeof(long long) * 2);
-        be.template launch_1d_range<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
-                                                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1}, sb.lo, sb.hi);
-        be.template launch_2d_range<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, sb.lo, sb.hi, d.T + 1);
-        be.d2h_async(host_counters + 2 * k, ctr, sizeof(long long) * 2);
-        be.record(sb.ev);
+#if defined(MAS_HOST_EMULATION)
+    const bool run_ahead = false;
+#else
+    // a solve that follows a one-round solve (the re-solves of outer rounds 2..max_outer usually are) would
+    // waste its run-ahead round, so run ahead only while the previous solve needed several rounds
+    const bool run_ahead = last_solve_rounds != 1;
+#endif
+    struct Marks { size_t p0, p1, s0, s1; };
+    Marks marks[2];
+    auto enqueue = [&](int r) {
+      Marks& mk = marks[r & 1];
+      mk.p0 = be.mark(); mk.s0 = stamp_launches.size();
+      // byte counts are per agent here and scaled by the round's active-agent count once it is known
+      launch_sweep(sweep_bytes(), 0, d.N);
+      launch_backward(backward_bytes(), 0, d.N);
+      be.template launch_2d_range<1>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
+      long long* ctr = counters + 2 * (r % kCounterRing);
+      long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
+      be.template launch_1d<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
+                                                    iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear}, d.N);
+      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      be.d2h_async(host_counters + 2 * (r % kCounterRing), ctr, sizeof(long long) * 2);
+      be.record(round_ev[r & 1]);
+      mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
+    };
+    long long n_before = d.N;
+    int enq = 0, rounds_this_solve = 0;
+    if (max_iterations > 0 && !timed_out(t0)) { enqueue(0); enq = 1; }
+    else if (max_iterations > 0) be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
+    for (int r = 0; r < enq; ++r) {
+      if (run_ahead && enq == r + 1 && r + 1 < max_iterations && !timed_out(t0)) { enqueue(r + 1); ++enq; }
+      be.wait(round_ev[r & 1]);
+      const long long* hc = host_counters + 2 * (r % kCounterRing);
+      const long long n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]);
+      stats.agent_iterations += n_before;           // every agent active at the start of a round executes one iLQR iteration
+      stats.converged_solves += hc[1];
+      stats.batch_iterations++; ++rounds_this_solve;
+      be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_before));
+      for (size_t q = marks[r & 1].s0; q < marks[r & 1].s1; ++q) stamp_launches[q].bytes *= static_cast<double>(n_before);
+      n_before = n_after;
+      if (n_after == 0) {                            // a round enqueued ahead runs on zero agents: nothing to account
+        if (enq > r + 1) { be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0); for (size_t q = marks[(r + 1) & 1].s0; q < marks[(r + 1) & 1].s1; ++q) stamp_launches[q].bytes = 0.0; }
+        break;
       }
-      if (!any) break;
-      for (size_t k = 0; k < subs.size(); ++k) {     // join: one small read-back per range and round
-        SubBatch& sb = subs[k];
-        if (sb.done) { if (timeout) be.wait(sb.ev); continue; }
-        be.wait(sb.ev);
-        sb.n_active = static_cast<long long>(reinterpret_cast<int*>(host_counters + 2 * k)[0]);
-        stats.converged_solves += host_counters[2 * k + 1];
-        if (sb.n_active == 0) sb.done = true;
+      if (enq == r + 1 && r + 1 < max_iterations) {
+        if (timed_out(t0)) { be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N); break; }
+        enqueue(r + 1); ++enq;
       }
-      stats.batch_iterations++;
-      if (timeout) break;
     }
-    be.use_main();
+    if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);   // drain a round that ran ahead
+    last_solve_rounds = rounds_this_solve;
   }
 
   double host_sum(const double* dev) {      // Solution.total_cost: serial sum in block order (nash.hpp:23-37)
@@ -484,7 +479,10 @@ class SolverImpl final : public SolverBase {
   unsigned long long* sweep_stamps = nullptr;
   size_t stamp_capacity = 0, stamp_used = 0;
   std::vector<StampedLaunch> stamp_launches;
-  std::vector<SubBatch> subs;
+  static constexpr int kCounterRing = 4;
+  typename Backend::Event round_ev[2]{};
+  bool round_events_made = false;
+  int last_solve_rounds = 0;
   HostStats stats;
 };
 
