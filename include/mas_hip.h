@@ -48,7 +48,9 @@ enum mas_hip_model {
   MAS_HIP_MODEL_LQR_IDENTITY      = 2, /* examples/multi_agent_lqr.cpp:21-76; analytic derivatives */
   MAS_HIP_MODEL_PENDULUM          = 3, /* examples/pendulum_swing_up.cpp:29-117, models/pendulum_model.hpp:8-20; FD */
   MAS_HIP_MODEL_SINGLE_TRACK_LANE = 4, /* examples/single_track_ocp.cpp:14-116; analytic except cross term */
-  MAS_HIP_MODEL_BICYCLE6          = 5  /* this repository's own 6-state model (BASELINE config 5) */
+  MAS_HIP_MODEL_BICYCLE6          = 5, /* this repository's own 6-state model (BASELINE config 5) */
+  MAS_HIP_MODEL_SINGLE_TRACK_LIMITED = 6 /* this repository's own: single track + function constraints (speed limit, v >= 0,
+                                            steering/acceleration coupling); exercises the augmented-Lagrangian branch */
 };
 
 /* per-agent exit status of the most recent solve (extension: the reference's solve()
@@ -88,8 +90,9 @@ const char* mas_hip_last_error(const mas_hip_solver*);   /* NULL handle: last cr
 
 /* ---- solver parameters: iLQR::set_params, ilqr.hpp:39-55 ----
  * keys "max_iterations", "tolerance", "max_ms" (required by the reference: params.at()),
- * optional "debug"; the penalty* keys are accepted and ignored (augmented-Lagrangian branch
- * is out of scope); unknown keys are ignored like the reference. */
+ * optional "debug", "penalty", "penalty_increase", "constraint_tolerance",
+ * "inequality_activation_tolerance" (augmented-Lagrangian branch, ilqr.hpp:47-54);
+ * unknown keys are ignored like the reference. */
 int mas_hip_set_param(mas_hip_solver*, const char* key, double value);
 /* fails with MAS_HIP_ERR_INVALID if a required key was never set (mirrors std::out_of_range) */
 int mas_hip_check_params(const mas_hip_solver*);

@@ -19,6 +19,7 @@ MODEL_LQR_IDENTITY = 2
 MODEL_PENDULUM = 3
 MODEL_SINGLE_TRACK_LANE = 4
 MODEL_BICYCLE6 = 5
+MODEL_SINGLE_TRACK_LIMITED = 6
 
 EXIT_CONVERGED, EXIT_MAX_ITER, EXIT_TIME, EXIT_NONFINITE = 0, 1, 2, 4
 

@@ -25,6 +25,16 @@ struct Dims {
   size_t Np;    // padded agent count (row stride)
 };
 
+// Augmented-Lagrangian state of the solver objects (ilqr.hpp:415-421,445-453), one per agent and persistent
+// across solves: multipliers lam[T*NEQ][Np], mu[T*NIN][Np], penalty rho[Np].  `on` is false for unconstrained
+// models and for the centralised strategy (the stacked OCP carries no constraint functions,
+// multi_agent_problem.hpp:52-127).
+struct ALView {
+  bool on = false;
+  double* lam = nullptr; double* mu = nullptr; double* rho = nullptr;
+  double act_tol = 1e-6;
+};
+
 // (uniform row pointer)[lane index]: lets the compiler address with a scalar base + 32-bit lane offset
 #define MAS_AT(base, row, a) ((base) + static_cast<size_t>(row) * d.Np)[static_cast<unsigned>(a)]
 // uniform (scalar) base pointer + 32-bit per-lane byte offset: the addressing form gfx950 executes with
@@ -57,6 +67,7 @@ struct RolloutCostBody {
   double* cost;          // [Np]
   double* merit;         // [Np] (current merit == objective without constraint functions, ilqr.hpp:379-407)
   const int* active;     // optional mask
+  ALView al;
   MAS_HD void operator()(int a) const {
     constexpr int NX = M::NX, NU = M::NU;
     if (active && !active[a]) return;
@@ -71,7 +82,23 @@ struct RolloutCostBody {
     }
     c += M::terminal_cost(x, P);
     cost[a] = c;
-    if (merit) merit[a] = c;
+    if (merit) {
+      double m = c;
+      if constexpr (M::NEQ + M::NIN > 0) {
+        if (al.on) {                                   // compute_merit adds the constraint terms AFTER the whole objective, step by step
+          const double rho = al.rho[a];
+          for (int t = 0; t < d.T; ++t) {
+            double xt[NX], ut[NU], lam[M::NEQ > 0 ? M::NEQ : 1], mu[M::NIN > 0 ? M::NIN : 1];
+            MAS_UNROLL for (int i = 0; i < NX; ++i) xt[i] = MAS_AT(X, t * NX + i, a);
+            MAS_UNROLL for (int i = 0; i < NU; ++i) ut[i] = MAS_AT(U, t * NU + i, a);
+            MAS_UNROLL for (int k = 0; k < M::NEQ; ++k) lam[k] = MAS_AT(al.lam, t * M::NEQ + k, a);
+            MAS_UNROLL for (int k = 0; k < M::NIN; ++k) mu[k] = MAS_AT(al.mu, t * M::NIN + k, a);
+            m = al_merit_step<M>(m, xt, ut, lam, mu, rho, al.act_tol, P);
+          }
+        }
+      }
+      merit[a] = m;
+    }
   }
 };
 
@@ -109,6 +136,7 @@ struct BackwardBody {
   double* Kfb;           // [T*nu*nx][Np], row (t, c*NU + i) = K_t(i, c)
   long long* reg_events; // [Np]
   const int* active;
+  ALView al;
   MAS_HD void operator()(int a) const {
     using L = DerivLayout<M>;
     constexpr int NX = M::NX, NU = M::NU;
@@ -126,6 +154,14 @@ struct BackwardBody {
       MAS_UNROLL for (int i = 0; i < L::ND; ++i) Dn[i] = MAS_TILE_AT(D, L::ND, tn, a, i);
       QFunction<M> q;
       assemble_q<M>(Dl, vx, vxx, q);
+      if constexpr (M::NEQ + M::NIN > 0) {
+        if (al.on) {
+          double lam[M::NEQ > 0 ? M::NEQ : 1], mu[M::NIN > 0 ? M::NIN : 1];
+          MAS_UNROLL for (int k2 = 0; k2 < M::NEQ; ++k2) lam[k2] = MAS_AT(al.lam, t * M::NEQ + k2, a);
+          MAS_UNROLL for (int k2 = 0; k2 < M::NIN; ++k2) mu[k2] = MAS_AT(al.mu, t * M::NIN + k2, a);
+          al_q_terms<M>(Dl, lam, mu, al.rho[a], al.act_tol, q);
+        }
+      }
       double Lfac[NU * NU], k[NU], K[NU * NX];
       regs += llt_ladder<NU>(q.quu, Lfac);
       gains_and_value<M>(q, Lfac, k, K, vx, vxx);
@@ -150,7 +186,9 @@ struct ForwardBody {
   double* Xs;            // [NA][(T+1)*nx][Np] trial trajectories
   double* Us;            // [NA][T*nu][Np]
   double* trial_merit;   // [NA][Np]
+  double* trial_obj;     // [NA][Np] objective of each trial (== merit without constraint functions; may be null then)
   const int* active;
+  ALView al;
   MAS_HD void operator()(int a, int j) const {
     constexpr int NX = M::NX, NU = M::NU;
     if (!active[a]) return;
@@ -192,7 +230,22 @@ struct ForwardBody {
       MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = K_n[i];
     }
     c += M::terminal_cost(x, P);
-    trial_merit[static_cast<size_t>(j) * d.Np + a] = c;
+    double m = c;
+    if constexpr (M::NEQ + M::NIN > 0) {
+      if (al.on) {                                     // compute_merit(x_trial, u_trial), ilqr.hpp:219,379-407
+        const double rho = al.rho[a];
+        for (int t = 0; t < d.T; ++t) {
+          double xt[NX], ut[NU], lam[M::NEQ > 0 ? M::NEQ : 1], mu[M::NIN > 0 ? M::NIN : 1];
+          MAS_UNROLL for (int i = 0; i < NX; ++i) xt[i] = MAS_AT(Xj, t * NX + i, a);
+          MAS_UNROLL for (int i = 0; i < NU; ++i) ut[i] = MAS_AT(Uj, t * NU + i, a);
+          MAS_UNROLL for (int k2 = 0; k2 < M::NEQ; ++k2) lam[k2] = MAS_AT(al.lam, t * M::NEQ + k2, a);
+          MAS_UNROLL for (int k2 = 0; k2 < M::NIN; ++k2) mu[k2] = MAS_AT(al.mu, t * M::NIN + k2, a);
+          m = al_merit_step<M>(m, xt, ut, lam, mu, rho, al.act_tol, P);
+        }
+      }
+    }
+    trial_merit[static_cast<size_t>(j) * d.Np + a] = m;
+    if (trial_obj) trial_obj[static_cast<size_t>(j) * d.Np + a] = c;
   }
 };
 
@@ -206,6 +259,8 @@ struct SelectBody {
   int* n_active;              // counter of agents still active after this iteration
   long long* n_converged;
   long long* clear;           // counter pair of the ring that the round after next will use: reset here
+  const double* trial_obj = nullptr;   // objective of the trials when it differs from the merit (constraint functions)
+  double* improvement_out = nullptr;   // non-null: termination is decided by ALUpdateBody after the multiplier update
   MAS_HD void operator()(int a) const {
     if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
     if (!active[a]) { alpha_sel[a] = -1; return; }
@@ -217,9 +272,10 @@ struct SelectBody {
     }
     const double improvement = cur - best;                  // 0 when no trial was accepted
     alpha_sel[a] = sel;
-    if (sel >= 0) { cost[a] = best; merit[a] = best; }      // cost == objective(best_x,best_u) == accepted merit
+    if (sel >= 0) { cost[a] = trial_obj ? trial_obj[static_cast<size_t>(sel) * d.Np + a] : best; merit[a] = best; }   // cost = objective(best_x,best_u); current_merit = best_merit
     const int it = iters_solve[a] + 1;
     iters_solve[a] = it; iters_total[a] += 1;
+    if (improvement_out) { improvement_out[a] = improvement; return; }
     if (improvement < tolerance) {                          // ilqr.hpp:269-271
       active[a] = 0; exit_code[a] = kExitConverged | (std::isfinite(best) ? 0 : kExitNonFinite);
       MAS_ATOMIC_ADD_I64(n_converged, 1LL);
@@ -245,6 +301,42 @@ struct CommitBody {
     const double* Uj = Us + static_cast<size_t>(j) * d.T * NU * d.Np;
     MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(X, t * NX + i, a) = MAS_AT(Xj, t * NX + i, a);
     if (t < d.T) { MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(U, t * NU + i, a) = MAS_AT(Uj, t * NU + i, a); }
+  }
+};
+
+// multiplier / penalty update and termination for constrained models, ilqr.hpp:236-260,269-271 (after commit)
+template <class M>
+struct ALUpdateBody {
+  Dims d; ModelParams P; double tolerance; int max_iterations; ALParams ap;
+  const double* X; const double* U; const double* improvement;
+  ALView al;
+  int* active; const int* iters_solve; int* exit_code; int* n_active; long long* n_converged;
+  MAS_HD void operator()(int a) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (!active[a]) return;
+    const double rho = al.rho[a];
+    double eqv = 0.0, inv = 0.0;
+    for (int t = 0; t < d.T; ++t) {
+      double xt[NX], ut[NU], lam[M::NEQ > 0 ? M::NEQ : 1], mu[M::NIN > 0 ? M::NIN : 1];
+      MAS_UNROLL for (int i = 0; i < NX; ++i) xt[i] = MAS_AT(X, t * NX + i, a);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) ut[i] = MAS_AT(U, t * NU + i, a);
+      MAS_UNROLL for (int k = 0; k < M::NEQ; ++k) lam[k] = MAS_AT(al.lam, t * M::NEQ + k, a);
+      MAS_UNROLL for (int k = 0; k < M::NIN; ++k) mu[k] = MAS_AT(al.mu, t * M::NIN + k, a);
+      al_update_step<M>(xt, ut, lam, mu, rho, eqv, inv, P);
+      MAS_UNROLL for (int k = 0; k < M::NEQ; ++k) MAS_AT(al.lam, t * M::NEQ + k, a) = lam[k];
+      MAS_UNROLL for (int k = 0; k < M::NIN; ++k) MAS_AT(al.mu, t * M::NIN + k, a) = mu[k];
+    }
+    const double eq_norm = sqrt(eqv), in_norm = sqrt(inv);
+    if (eq_norm > ap.constraint_tolerance || in_norm > ap.constraint_tolerance) al.rho[a] = rho * ap.penalty_increase;
+    const double imp = improvement[a];
+    if (imp < tolerance && eq_norm < ap.constraint_tolerance && in_norm < ap.constraint_tolerance) {
+      active[a] = 0; exit_code[a] = kExitConverged;
+      MAS_ATOMIC_ADD_I64(n_converged, 1LL);
+    } else if (iters_solve[a] >= max_iterations) {
+      active[a] = 0; exit_code[a] = kExitMaxIter;
+    } else {
+      MAS_ATOMIC_ADD_INT(n_active, 1);
+    }
   }
 };
 

@@ -164,6 +164,37 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       }
     }
   }
+  // function constraints: residual and central-difference Jacobians (finite_differences.hpp:289-345, eps = 1e-6)
+  if constexpr (M::NEQ > 0) {
+    const double eps = 1e-6;
+    double cp[M::NEQ], cm[M::NEQ];
+    M::equality(x, u, D + L::oEq, P);
+    MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      perturb1<NX>(x, i, +eps, xp); M::equality(xp, u, cp, P);
+      perturb1<NX>(x, i, -eps, xm); M::equality(xm, u, cm, P);
+      MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJx + i * M::NEQ + r] = (cp[r] - cm[r]) / (2 * eps);
+    }
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      perturb1<NU>(u, i, +eps, up); M::equality(x, up, cp, P);
+      perturb1<NU>(u, i, -eps, um); M::equality(x, um, cm, P);
+      MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJu + i * M::NEQ + r] = (cp[r] - cm[r]) / (2 * eps);
+    }
+  }
+  if constexpr (M::NIN > 0) {
+    const double eps = 1e-6;
+    double cp[M::NIN], cm[M::NIN];
+    M::inequality(x, u, D + L::oIn, P);
+    MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      perturb1<NX>(x, i, +eps, xp); M::inequality(xp, u, cp, P);
+      perturb1<NX>(x, i, -eps, xm); M::inequality(xm, u, cm, P);
+      MAS_UNROLL for (int r = 0; r < M::NIN; ++r) D[L::oInJx + i * M::NIN + r] = (cp[r] - cm[r]) / (2 * eps);
+    }
+    MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      perturb1<NU>(u, i, +eps, up); M::inequality(x, up, cp, P);
+      perturb1<NU>(u, i, -eps, um); M::inequality(x, um, cm, P);
+      MAS_UNROLL for (int r = 0; r < M::NIN; ++r) D[L::oInJu + i * M::NIN + r] = (cp[r] - cm[r]) / (2 * eps);
+    }
+  }
 }
 
 // in-place  V = 0.5 * (V + V^T)  in the order Eigen executes the reference's aliased
@@ -373,6 +404,99 @@ MAS_HD void gains_and_value(const QFunction<M>& q, const double* Lfac, double* k
   mat_AB<NX, NU, NX>(KtQuu, K, txx);
   MAS_UNROLL for (int i = 0; i < NX * NX; ++i) vxx[i] = vxx[i] + txx[i];
   symmetrise_inplace<NX>(vxx);
+}
+
+// ------------------------------------------------------- augmented Lagrangian (ilqr.hpp) ------
+struct ALParams { double penalty_increase, constraint_tolerance, activation_tolerance; };
+
+// Q-function terms of the constraints at one step, ilqr.hpp:121-170.  lam / mu: this step's multipliers.
+template <class M>
+MAS_HD void al_q_terms(const double* D, const double* lam, const double* mu, double rho, double act_tol, QFunction<M>& q) {
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU;
+  if constexpr (M::NEQ > 0) {
+    constexpr int ME = M::NEQ;
+    const double* c = D + L::oEq; const double* Jx = D + L::oEqJx; const double* Ju = D + L::oEqJu;
+    double dual[ME];
+    MAS_UNROLL for (int k = 0; k < ME; ++k) dual[k] = lam[k] + rho * c[k];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { double a = 0.0; MAS_UNROLL for (int k = 0; k < ME; ++k) a += Jx[i * ME + k] * dual[k]; q.qx[i] += a; }
+    MAS_UNROLL for (int i = 0; i < NU; ++i) { double a = 0.0; MAS_UNROLL for (int k = 0; k < ME; ++k) a += Ju[i * ME + k] * dual[k]; q.qu[i] += a; }
+    MAS_UNROLL for (int j = 0; j < NX; ++j) { MAS_UNROLL for (int i = 0; i < NX; ++i) {
+      double a = 0.0; MAS_UNROLL for (int k = 0; k < ME; ++k) a += (rho * Jx[i * ME + k]) * Jx[j * ME + k]; q.qxx[j * NX + i] += a; } }
+    MAS_UNROLL for (int j = 0; j < NX; ++j) { MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      double a = 0.0; MAS_UNROLL for (int k = 0; k < ME; ++k) a += (rho * Ju[i * ME + k]) * Jx[j * ME + k]; q.qux[j * NU + i] += a; } }
+    MAS_UNROLL for (int j = 0; j < NU; ++j) { MAS_UNROLL for (int i = 0; i < NU; ++i) {
+      double a = 0.0; MAS_UNROLL for (int k = 0; k < ME; ++k) a += (rho * Ju[i * ME + k]) * Ju[j * ME + k]; q.quu[j * NU + i] += a; } }
+  }
+  if constexpr (M::NIN > 0) {
+    constexpr int MI = M::NIN;
+    const double* g = D + L::oIn; const double* Jx = D + L::oInJx; const double* Ju = D + L::oInJu;
+    double dual[MI], act[MI];
+    bool any = false;
+    MAS_UNROLL for (int k = 0; k < MI; ++k) {
+      const double slack = g[k] > 0.0 ? g[k] : 0.0;
+      act[k] = (g[k] > -act_tol) ? 1.0 : 0.0;
+      dual[k] = mu[k] * act[k] + rho * slack * act[k];
+      any = any || (act[k] != 0.0);
+    }
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { double a = 0.0; MAS_UNROLL for (int k = 0; k < MI; ++k) a += Jx[i * MI + k] * dual[k]; q.qx[i] += a; }
+    MAS_UNROLL for (int i = 0; i < NU; ++i) { double a = 0.0; MAS_UNROLL for (int k = 0; k < MI; ++k) a += Ju[i * MI + k] * dual[k]; q.qu[i] += a; }
+    if (any) {                                          // ilqr.hpp:163
+      MAS_UNROLL for (int j = 0; j < NX; ++j) { MAS_UNROLL for (int i = 0; i < NX; ++i) {
+        double a = 0.0; MAS_UNROLL for (int k = 0; k < MI; ++k) a += ((rho * Jx[i * MI + k]) * act[k]) * Jx[j * MI + k]; q.qxx[j * NX + i] += a; } }
+      MAS_UNROLL for (int j = 0; j < NX; ++j) { MAS_UNROLL for (int i = 0; i < NU; ++i) {
+        double a = 0.0; MAS_UNROLL for (int k = 0; k < MI; ++k) a += ((rho * Ju[i * MI + k]) * act[k]) * Jx[j * MI + k]; q.qux[j * NU + i] += a; } }
+      MAS_UNROLL for (int j = 0; j < NU; ++j) { MAS_UNROLL for (int i = 0; i < NU; ++i) {
+        double a = 0.0; MAS_UNROLL for (int k = 0; k < MI; ++k) a += ((rho * Ju[i * MI + k]) * act[k]) * Ju[j * MI + k]; q.quu[j * NU + i] += a; } }
+    }
+  }
+}
+
+// merit contribution of one step added to `merit` in the reference's order, ilqr.hpp:386-404
+template <class M>
+MAS_HD double al_merit_step(double merit, const double* x, const double* u, const double* lam, const double* mu, double rho, double act_tol,
+                            const ModelParams& P) {
+  if constexpr (M::NEQ > 0) {
+    double r[M::NEQ]; M::equality(x, u, r, P);
+    double dot = 0.0, sq = 0.0;
+    MAS_UNROLL for (int k = 0; k < M::NEQ; ++k) { dot += lam[k] * r[k]; sq += r[k] * r[k]; }
+    merit += dot + 0.5 * rho * sq;
+  }
+  if constexpr (M::NIN > 0) {
+    double r[M::NIN]; M::inequality(x, u, r, P);
+    double dot = 0.0, sq = 0.0;
+    MAS_UNROLL for (int k = 0; k < M::NIN; ++k) {
+      const double slack = r[k] > 0.0 ? r[k] : 0.0;
+      const double active = (r[k] > -act_tol) ? 1.0 : 0.0;
+      const double active_slack = slack * active, weighted = mu[k] * active;
+      dot += weighted * active_slack; sq += active_slack * active_slack;
+    }
+    merit += dot;
+    merit += 0.5 * rho * sq;
+  }
+  return merit;
+}
+
+// multiplier update of one step, ilqr.hpp:239-254; returns the squared violations through eqv / inv
+template <class M>
+MAS_HD void al_update_step(const double* x, const double* u, double* lam, double* mu, double rho, double& eqv, double& inv, const ModelParams& P) {
+  if constexpr (M::NEQ > 0) {
+    double r[M::NEQ]; M::equality(x, u, r, P);
+    double sq = 0.0;
+    MAS_UNROLL for (int k = 0; k < M::NEQ; ++k) { lam[k] += rho * r[k]; sq += r[k] * r[k]; }
+    eqv += sq;
+  }
+  if constexpr (M::NIN > 0) {
+    double r[M::NIN]; M::inequality(x, u, r, P);
+    double sq = 0.0;
+    MAS_UNROLL for (int k = 0; k < M::NIN; ++k) {
+      const double positive = r[k] > 0.0 ? r[k] : 0.0;
+      const double v = mu[k] + rho * positive;
+      mu[k] = v > 0.0 ? v : 0.0;
+      sq += positive * positive;
+    }
+    inv += sq;
+  }
 }
 
 // ------------------------------------------------------------------- forward step ------

@@ -25,13 +25,21 @@ struct ModelParams {
   double p[16];
 };
 
+// Function constraints h(x,u) = 0 (NEQ rows) and g(x,u) <= 0 (NIN rows), ocp.hpp:61-68.  No shipped reference
+// example sets one; models without constraints inherit these empty hooks.
+struct NoConstraints {
+  static constexpr int NEQ = 0, NIN = 0;
+  MAS_HD static void equality(const double*, const double*, double*, const ModelParams&) {}
+  MAS_HD static void inequality(const double*, const double*, double*, const ModelParams&) {}
+};
+
 // ---------------------------------------------------------------------------------------
 // Single-track circular-track workload.
 //   dynamics: examples/models/single_track_model.hpp:23-44
 //   cost / bounds / constants: examples/multi_agent_single_track.cpp:46-67,103-110
 //   no analytic hooks are set by that example (:46-69) => everything FD
 // params: [0] track_radius [1] target_velocity [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L
-struct SingleTrack {
+struct SingleTrack : NoConstraints {
   static constexpr int NX = 4, NU = 2;
   static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
                         kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
@@ -67,7 +75,7 @@ struct SingleTrack {
 // derivative analytic (:35-41,46-71).
 struct NoCtl {};
 
-struct LqrIdentity {
+struct LqrIdentity : NoConstraints {
   static constexpr int NX = 4, NU = 4;
   using Ctl = NoCtl;
   MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
@@ -121,7 +129,7 @@ struct LqrIdentity {
 // ---------------------------------------------------------------------------------------
 // Pendulum swing-up: examples/models/pendulum_model.hpp:8-20, examples/pendulum_swing_up.cpp:29-117.
 // No analytic hooks are wired by the example => FD.  params: [0] horizon_d (the T in s = k/(T-1)).
-struct Pendulum {
+struct Pendulum : NoConstraints {
   static constexpr int NX = 2, NU = 1;
   using Ctl = NoCtl;
   MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
@@ -166,7 +174,7 @@ struct Pendulum {
 // (models/single_track_model.hpp:49-82) and l_x,l_u,l_xx,l_uu (:62-94); the cross term and
 // the (zero) terminal derivatives stay FD.
 // params: [0] desired_velocity [1] w_lane [2] w_speed [3] w_delta [4] w_acc [6] L
-struct SingleTrackLane {
+struct SingleTrackLane : NoConstraints {
   static constexpr int NX = 4, NU = 2;
   static constexpr bool kAnalyticA = true, kAnalyticB = true, kAnalyticLx = true, kAnalyticLu = true,
                         kAnalyticLxx = true, kAnalyticLuu = true, kAnalyticLux = false, kAnalyticTerm = false;
@@ -212,7 +220,7 @@ struct SingleTrackLane {
 // states and their rates as controls; circular-track cost as in the single-track example.
 //   state [X, Y, psi, v, delta, a], control [delta_rate, jerk]
 // params: [0] R [1] vt [2] w_track [3] w_speed [4] w_delta [5] w_acc [6] L [7] w_rate
-struct Bicycle6 {
+struct Bicycle6 : NoConstraints {
   static constexpr int NX = 6, NU = 2;
   using Ctl = NoCtl;
   MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
@@ -238,12 +246,26 @@ struct Bicycle6 {
   MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
 };
 
+// ---------------------------------------------------------------------------------------
+// single track + function constraints: THIS REPOSITORY'S OWN workload for the augmented-Lagrangian branch of
+// iLQR (ilqr.hpp:121-170,236-260,379-407).  Dynamics, cost, bounds of SingleTrack plus
+//   h(x,u) = [ delta - p[9]*a ]        g(x,u) = [ v - p[8], -v ]
+struct SingleTrackLimited : SingleTrack {
+  static constexpr int NEQ = 1, NIN = 2;
+  MAS_HD static void equality(const double*, const double* u, double* out, const ModelParams& P) { out[0] = u[0] - P.p[9] * u[1]; }
+  MAS_HD static void inequality(const double* x, const double*, double* out, const ModelParams& P) { out[0] = x[3] - P.p[8]; out[1] = -x[3]; }
+};
+
 // number of doubles the linearisation of one (agent, t) produces: A,B,l_x,l_u,l_xx,l_uu,l_ux
 template <class M>
 struct DerivLayout {
   static constexpr int NX = M::NX, NU = M::NU;
+  static constexpr int NEQ = M::NEQ, NIN = M::NIN;
   static constexpr int oA = 0, oB = oA + NX * NX, oLx = oB + NX * NU, oLu = oLx + NX, oLxx = oLu + NU,
-                       oLuu = oLxx + NX * NX, oLux = oLuu + NU * NU, ND = oLux + NU * NX;
+                       oLuu = oLxx + NX * NX, oLux = oLuu + NU * NU, oCore = oLux + NU * NX,
+                       // constraint residuals and Jacobians (column-major m x nx, m x nu), only for constrained models
+                       oEq = oCore, oEqJx = oEq + NEQ, oEqJu = oEqJx + NEQ * NX, oIn = oEqJu + NEQ * NU, oInJx = oIn + NIN,
+                       oInJu = oInJx + NIN * NX, ND = oInJu + NIN * NU;
 };
 
 inline void model_default_params(int model_id, int T, double* p) {
@@ -253,6 +275,7 @@ inline void model_default_params(int model_id, int T, double* p) {
     case 3: p[0] = static_cast<double>(T); break;                                                       // pendulum_swing_up.cpp:62
     case 4: p[0] = 1.0; p[1] = 10.0; p[2] = 1.0; p[3] = 0.1; p[4] = 0.1; p[6] = 2.5; break;              // single_track_ocp.cpp:34-40
     case 5: p[0] = 20.0; p[1] = 5.0; p[2] = 1.0; p[3] = 1.0; p[4] = 0.001; p[5] = 0.001; p[6] = 2.5; p[7] = 0.001; break;
+    case 6: p[0] = 20.0; p[1] = 5.0; p[2] = 1.0; p[3] = 1.0; p[4] = 0.001; p[5] = 0.001; p[6] = 2.5; p[8] = 4.5; p[9] = 0.1; break;
     default: break;
   }
 }

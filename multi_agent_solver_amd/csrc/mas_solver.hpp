@@ -65,7 +65,11 @@ class SolverBase {
     else if (key == "tolerance") { tolerance = value; has_tolerance = true; }
     else if (key == "max_ms") { max_ms = value; has_max_ms = true; }
     else if (key == "debug") { debug = value > 0.5; }
-    else return false;   // penalty*, constraint_tolerance, ... and unknown keys: ignored
+    else if (key == "penalty") { penalty = value; penalty_set = true; on_penalty_changed(); }                 // ilqr.hpp:47-54
+    else if (key == "penalty_increase") { penalty_increase = value; }
+    else if (key == "constraint_tolerance") { constraint_tolerance = value; }
+    else if (key == "inequality_activation_tolerance") { inequality_activation_tolerance = value; }
+    else return false;   // unknown keys: ignored like the reference
     return true;
   }
   bool params_complete() const { return has_max_iterations && has_tolerance && has_max_ms; }
@@ -78,11 +82,16 @@ class SolverBase {
   double max_ms = std::numeric_limits<double>::infinity();
   bool debug = false;
   bool has_max_iterations = false, has_tolerance = false, has_max_ms = false;
+  // augmented-Lagrangian parameters, defaults of ilqr.hpp:31-34
+  double penalty = 10.0, penalty_increase = 5.0, constraint_tolerance = 1e-4, inequality_activation_tolerance = 1e-6;
+  bool penalty_set = false;
+  virtual void on_penalty_changed() {}
 };
 
 template <class M>
 class SolverImpl final : public SolverBase {
   static constexpr int NX = M::NX, NU = M::NU;
+  static constexpr bool kConstrained = (M::NEQ + M::NIN) > 0;
   using L = DerivLayout<M>;
 
  public:
@@ -110,6 +119,12 @@ class SolverImpl final : public SolverBase {
     reg_events = static_cast<long long*>(be.alloc(sizeof(long long) * Np));
     counters = static_cast<long long*>(be.alloc(sizeof(long long) * 32));
     central = static_cast<CentralState*>(be.alloc(sizeof(CentralState)));
+    if constexpr (kConstrained) {
+      if (M::NEQ > 0) al_lam = dalloc(static_cast<size_t>(T) * M::NEQ * Np);
+      if (M::NIN > 0) al_mu = dalloc(static_cast<size_t>(T) * M::NIN * Np);
+      al_rho = dalloc(Np); improvement = dalloc(Np); trial_obj = dalloc(static_cast<size_t>(kNumAlphas) * Np);
+      al_rho_dirty = true;
+    }
     const size_t stage_elems = static_cast<size_t>(d.N) * std::max<size_t>(static_cast<size_t>(T + 1) * NX, static_cast<size_t>(T) * std::max(L::ND, NU * NX));
     stage = dalloc(stage_elems);
     host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 32));
@@ -142,7 +157,7 @@ class SolverImpl final : public SolverBase {
   }
   void initialize_problem() override {
     require(have_x0, "initial states not set");
-    be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
+    be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
     if (!radii) radii = dalloc(d.Np);
     initialized = true; rollout_consistent = true;
   }
@@ -161,14 +176,16 @@ class SolverImpl final : public SolverBase {
   // ---------------------------------------------------------------- N x iLQR::solve ------
   void solve() override { Timer tm(*this); solve_all(); }
 
-  void run_sequential(int max_outer) override {          // nash.hpp:74-90
+  void run_sequential(int max_outer) override {
+    reset_solver_state();   // the strategy creates fresh solver objects (nash.hpp:78-84)          // nash.hpp:74-90
     Timer tm(*this);
     ensure_initialized();
     for (int outer = 0; outer < max_outer; ++outer) solve_all();   // update_initial_with_best (nash.hpp:66-71) has no device-side effect
     last_total_valid = false;
   }
 
-  void run_trust_region(int max_outer) override {        // nash.hpp:182-248
+  void run_trust_region(int max_outer) override {
+    reset_solver_state();   // the strategy creates fresh solver objects (nash.hpp:78-84)        // nash.hpp:182-248
     Timer tm(*this);
     ensure_initialized();
     ensure_snapshots();
@@ -182,7 +199,8 @@ class SolverImpl final : public SolverBase {
     last_total_valid = false;
   }
 
-  void run_line_search(int max_outer) override {         // nash.hpp:92-180
+  void run_line_search(int max_outer) override {
+    reset_solver_state();   // the strategy creates fresh solver objects (nash.hpp:78-84)         // nash.hpp:92-180
     Timer tm(*this);
     ensure_initialized();
     ensure_snapshots();
@@ -212,6 +230,8 @@ class SolverImpl final : public SolverBase {
 
   void run_centralized() override {                      // centralized.hpp:18-38, block-diagonal reading
     Timer tm(*this);
+    struct AlOff { bool& f; bool old; ~AlOff() { f = old; } } al_off{al_enabled, al_enabled};
+    al_enabled = false;                                  // build_global_ocp stacks no constraint functions
     require(have_x0, "initial states not set");
     require(d.N <= kCentralMaxAgents, "centralized strategy supports at most 1024 agents per device");
     be.zero(U, sizeof(double) * d.T * NU * d.Np);       // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109)
@@ -335,6 +355,10 @@ class SolverImpl final : public SolverBase {
 #if defined(MAS_HOST_EMULATION)
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
 #else
+    if constexpr (kConstrained) {     // constrained test workloads: plain body (tile = ND doubles incl. constraint Jacobians)
+      be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
+      return;
+    }
     be.begin("sweep", bytes);
     unsigned long long* stamp = nullptr;
     const dim3 grid((hi - lo + 63) / 64, (d.T + 3) / 4);
@@ -356,19 +380,40 @@ class SolverImpl final : public SolverBase {
   void launch_backward(double bytes) { launch_backward(bytes, 0, d.N); }
   void launch_backward(double bytes, int lo, int hi) {
 #if defined(MAS_HOST_EMULATION)
-    be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active}, lo, hi, bytes);
+    be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active, al_view(al_enabled)}, lo, hi, bytes);
 #else
+    if constexpr (kConstrained) {     // the 16-lane tile kernel covers the unconstrained recursion only
+      be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active, al_view(al_enabled)}, lo, hi, bytes);
+      return;
+    }
     be.begin("backward", bytes);
     be.launch_kernel(mas_backward_tile_kernel<M>, dim3((hi - lo + 3) / 4), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
     be.end();
 #endif
   }
 
+  ALView al_view(bool on) const {
+    ALView v;
+    if constexpr (kConstrained) { v.on = on; v.lam = al_lam; v.mu = al_mu; v.rho = al_rho; v.act_tol = inequality_activation_tolerance; }
+    return v;
+  }
+  // a freshly constructed iLQR: no multipliers, penalty_parameter = 10 or the "penalty" key (ilqr.hpp:31,47-48)
+  void reset_solver_state() {
+    if constexpr (kConstrained) {
+      if (al_lam) be.zero(al_lam, sizeof(double) * d.T * M::NEQ * d.Np);
+      if (al_mu) be.zero(al_mu, sizeof(double) * d.T * M::NIN * d.Np);
+      al_rho_dirty = true;
+    }
+  }
+  void on_penalty_changed() override { al_rho_dirty = true; }
+  void sync_penalty() { if constexpr (kConstrained) { if (al_rho_dirty) { fill(al_rho, penalty); al_rho_dirty = false; } } }
+
   ForwardBody<M> make_forward() const {
     ForwardBody<M> f;
     f.d = d; f.dt = dt; f.P = P; f.clamp = clamp;
     for (int i = 0; i < NU; ++i) { f.lb[i] = lb[i]; f.ub[i] = ub[i]; }
     f.x0 = x0; f.X = X; f.U = U; f.kff = kff; f.Kfb = Kfb; f.Xs = Xs; f.Us = Us; f.trial_merit = trial_merit; f.active = active;
+    f.trial_obj = (kConstrained && al_enabled) ? trial_obj : nullptr; f.al = al_view(al_enabled);
     return f;
   }
 
@@ -387,8 +432,9 @@ class SolverImpl final : public SolverBase {
     // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
     // rollout and cost (same kernels, same arithmetic, bit for bit), so it is only redone when the
     // controls were replaced from outside.
+    if (kConstrained && al_enabled) { sync_penalty(); rollout_consistent = false; }   // merit depends on the current multipliers
     if (!rollout_consistent) {
-      be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr}, d.N);
+      be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
       rollout_consistent = true;
     } else {
       be.d2d(merit, cost, sizeof(double) * d.Np);   // current_merit = compute_merit(x,u) == objective (ilqr.hpp:78)
@@ -416,9 +462,17 @@ class SolverImpl final : public SolverBase {
       be.template launch_2d_range<1>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
+      const bool al_round = kConstrained && al_enabled;
       be.template launch_1d<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
-                                                    iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear}, d.N);
+                                                    iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
+                                                    al_round ? trial_obj : nullptr, al_round ? improvement : nullptr}, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      if constexpr (kConstrained) {
+        if (al_round)
+          be.template launch_1d<1>("al_update", ALUpdateBody<M>{d, P, tolerance, max_iterations, ALParams{penalty_increase, constraint_tolerance, inequality_activation_tolerance},
+                                                               X, U, improvement, al_view(true), active, iters_solve, exit_code,
+                                                               reinterpret_cast<int*>(ctr), ctr + 1}, d.N);
+      }
       be.d2h_async(host_counters + 2 * (r % kCounterRing), ctr, sizeof(long long) * 2);
       be.record(round_ev[r & 1]);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
@@ -466,6 +520,8 @@ class SolverImpl final : public SolverBase {
   double *x0 = nullptr, *X = nullptr, *U = nullptr, *D = nullptr, *kff = nullptr, *Kfb = nullptr, *Xs = nullptr, *Us = nullptr;
   double *trial_merit = nullptr, *cost = nullptr, *merit = nullptr, *x0_saved = nullptr, *U_saved = nullptr, *stage = nullptr;
   double *Dsoa = nullptr;
+  double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
+  bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
@@ -493,6 +549,7 @@ inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* ex
     case 3: return std::make_unique<SolverImpl<Pendulum>>(desc, external_stream);
     case 4: return std::make_unique<SolverImpl<SingleTrackLane>>(desc, external_stream);
     case 5: return std::make_unique<SolverImpl<Bicycle6>>(desc, external_stream);
+    case 6: return std::make_unique<SolverImpl<SingleTrackLimited>>(desc, external_stream);
     default: return nullptr;
   }
 }
@@ -505,6 +562,7 @@ inline bool model_dims(int model_id, int* nx, int* nu) {
     case 3: a = Pendulum::NX; b = Pendulum::NU; break;
     case 4: a = SingleTrackLane::NX; b = SingleTrackLane::NU; break;
     case 5: a = Bicycle6::NX; b = Bicycle6::NU; break;
+    case 6: a = SingleTrackLimited::NX; b = SingleTrackLimited::NU; break;
     default: return false;
   }
   if (nx) *nx = a;

@@ -334,13 +334,44 @@ void mas_finite_differences_gradient(const mas_ocp* o, const double* x0, const d
   free(Up); free(Xp);
 }
 
+/* compute_constraints_state_jacobian / _control_jacobian, finite_differences.hpp:289-345: central
+ * differences with eps = 1e-6 (the reference first evaluates the constraint once for its size). */
+static void eval_constraint(const mas_ocp* o, int which, const double* x, const double* u, double* out) {
+  if (which == 0) o->equality_constraints(o, x, u, out); else o->inequality_constraints(o, x, u, out);
+}
+void mas_fd_constraints_state_jacobian(const mas_ocp* o, int which, const double* x, const double* u, double* J) {
+  const int n = o->state_dim, m = which == 0 ? o->eq_dim : o->ineq_dim; const double eps = 1e-6;
+  double* w = dalloc((size_t)n + 2 * m); double *xp = w, *fp = w + n, *fm = w + n + m;
+  for (int i = 0; i < n; ++i) {
+    perturb1(x, n, i, +eps, xp); eval_constraint(o, which, xp, u, fp);
+    perturb1(x, n, i, -eps, xp); eval_constraint(o, which, xp, u, fm);
+    for (int r = 0; r < m; ++r) J[(size_t)i * m + r] = (fp[r] - fm[r]) / (2 * eps);
+  }
+  free(w);
+}
+void mas_fd_constraints_control_jacobian(const mas_ocp* o, int which, const double* x, const double* u, double* J) {
+  const int p = o->control_dim, m = which == 0 ? o->eq_dim : o->ineq_dim; const double eps = 1e-6;
+  double* w = dalloc((size_t)p + 2 * m); double *up = w, *fp = w + p, *fm = w + p + m;
+  for (int i = 0; i < p; ++i) {
+    perturb1(u, p, i, +eps, up); eval_constraint(o, which, x, up, fp);
+    perturb1(u, p, i, -eps, up); eval_constraint(o, which, x, up, fm);
+    for (int r = 0; r < m; ++r) J[(size_t)i * m + r] = (fp[r] - fm[r]) / (2 * eps);
+  }
+  free(w);
+}
+
 /* ==================================================================== iLQR */
 
 void mas_ilqr_init(mas_ilqr* s) {
   memset(s, 0, sizeof(*s));
   s->max_iterations = 50; s->tolerance = 1e-6; s->max_ms = INFINITY; s->debug = 0;  /* ilqr.hpp:26-37 */
+  s->penalty_parameter = 10.0; s->penalty_increase = 5.0; s->constraint_tolerance = 1e-4; s->inequality_activation_tolerance = 1e-6;
 }
-void mas_ilqr_free(mas_ilqr* s) { free(s->ws); s->ws = NULL; }
+void mas_ilqr_free(mas_ilqr* s) { free(s->ws); s->ws = NULL; free(s->eq_multipliers); free(s->ineq_multipliers); s->eq_multipliers = s->ineq_multipliers = NULL; }
+void mas_ilqr_set_al_params(mas_ilqr* s, double penalty, double penalty_increase, double constraint_tolerance, double inequality_activation_tolerance) {
+  s->penalty_parameter = penalty; s->penalty_increase = penalty_increase; s->constraint_tolerance = constraint_tolerance;
+  s->inequality_activation_tolerance = inequality_activation_tolerance;
+}
 void mas_ilqr_set_params(mas_ilqr* s, int max_iterations, double tolerance, double max_ms, int debug) {
   s->max_iterations = max_iterations; s->tolerance = tolerance; s->max_ms = max_ms; s->debug = debug;
 }
@@ -543,8 +574,121 @@ static double now_ms(void) {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-/* iLQR::solve, ilqr.hpp:58-273, for problems without constraint functions (every shipped
- * example): merit == objective (ilqr.hpp:379-407), multiplier/penalty updates are no-ops. */
+/* compute_merit, ilqr.hpp:379-407 */
+double mas_ilqr_compute_merit(const mas_ilqr* s, const mas_ocp* o, const double* X, const double* U) {
+  const int T = o->horizon_steps, nx = o->state_dim, nu = o->control_dim;
+  const int me = o->equality_constraints ? o->eq_dim : 0, mi = o->inequality_constraints ? o->ineq_dim : 0;
+  double merit = mas_ocp_objective(o, X, U);
+  if (me == 0 && mi == 0) return merit;
+  double r[16];
+  for (int t = 0; t < T; ++t) {
+    if (me > 0) {
+      o->equality_constraints(o, X + (size_t)t * nx, U + (size_t)t * nu, r);
+      double dot = 0.0, sq = 0.0;
+      for (int k = 0; k < me; ++k) { dot += s->eq_multipliers[(size_t)t * me + k] * r[k]; sq += r[k] * r[k]; }
+      merit += dot + 0.5 * s->penalty_parameter * sq;
+    }
+    if (mi > 0) {
+      o->inequality_constraints(o, X + (size_t)t * nx, U + (size_t)t * nu, r);
+      double dot = 0.0, sq = 0.0;
+      for (int k = 0; k < mi; ++k) {
+        const double slack = r[k] > 0.0 ? r[k] : 0.0;                                        /* cwiseMax(0) */
+        const double active = (r[k] > -s->inequality_activation_tolerance) ? 1.0 : 0.0;
+        const double active_slack = slack * active, weighted = s->ineq_multipliers[(size_t)t * mi + k] * active;
+        dot += weighted * active_slack; sq += active_slack * active_slack;
+      }
+      merit += dot;
+      merit += 0.5 * s->penalty_parameter * sq;
+    }
+  }
+  return merit;
+}
+
+/* resize of the multiplier storage, ilqr.hpp:325-369: kept when the shape is unchanged, zero otherwise */
+static void al_resize(mas_ilqr* s, int T, int me, int mi) {
+  if (s->mult_T != T || s->mult_eq_dim != me) { free(s->eq_multipliers); s->eq_multipliers = me > 0 ? dalloc((size_t)T * me) : NULL; }
+  if (s->mult_T != T || s->mult_ineq_dim != mi) { free(s->ineq_multipliers); s->ineq_multipliers = mi > 0 ? dalloc((size_t)T * mi) : NULL; }
+  s->mult_T = T; s->mult_eq_dim = me; s->mult_ineq_dim = mi;
+}
+
+/* augmented-Lagrangian terms of the Q-function at one step, ilqr.hpp:121-170 */
+static void al_terms(const mas_ilqr* s, const mas_ocp* o, const double* x, const double* u, int t, step_ws* w) {
+  const int nx = w->nx, nu = w->nu;
+  const int me = o->equality_constraints ? o->eq_dim : 0, mi = o->inequality_constraints ? o->ineq_dim : 0;
+  const double rho = s->penalty_parameter;
+  double res[16], dual[16], act[16], Jx[16 * 16], Ju[16 * 16];
+  for (int which = 0; which < 2; ++which) {
+    const int m = which == 0 ? me : mi;
+    if (m == 0) continue;
+    eval_constraint(o, which, x, u, res);
+    mas_xu_mat_fn jx = which == 0 ? o->equality_constraints_state_jacobian : o->inequality_constraints_state_jacobian;
+    mas_xu_mat_fn ju = which == 0 ? o->equality_constraints_control_jacobian : o->inequality_constraints_control_jacobian;
+    if (jx) jx(o, x, u, Jx); else mas_fd_constraints_state_jacobian(o, which, x, u, Jx);
+    if (ju) ju(o, x, u, Ju); else mas_fd_constraints_control_jacobian(o, which, x, u, Ju);
+    int any_active = 0;
+    for (int k = 0; k < m; ++k) {
+      if (which == 0) { dual[k] = s->eq_multipliers[(size_t)t * m + k] + rho * res[k]; act[k] = 1.0; any_active = 1; }
+      else {
+        const double slack = res[k] > 0.0 ? res[k] : 0.0;
+        act[k] = (res[k] > -s->inequality_activation_tolerance) ? 1.0 : 0.0;
+        dual[k] = s->ineq_multipliers[(size_t)t * m + k] * act[k] + rho * slack * act[k];
+        if (act[k] != 0.0) any_active = 1;
+      }
+    }
+    /* q_x += Jx^T dual ; q_u += Ju^T dual */
+    for (int i = 0; i < nx; ++i) { double a = 0.0; for (int k = 0; k < m; ++k) a += Jx[(size_t)i * m + k] * dual[k]; w->qx[i] += a; }
+    for (int i = 0; i < nu; ++i) { double a = 0.0; for (int k = 0; k < m; ++k) a += Ju[(size_t)i * m + k] * dual[k]; w->qu[i] += a; }
+    if (!any_active) continue;                       /* :163 (equalities always contribute) */
+    /* q_xx += (rho Jx^T) [diag(active)] Jx  etc.; for equalities there is no diag factor */
+    for (int j = 0; j < nx; ++j) for (int i = 0; i < nx; ++i) {
+      double a = 0.0;
+      for (int k = 0; k < m; ++k) { double l = rho * Jx[(size_t)i * m + k]; if (which == 1) l = l * act[k]; a += l * Jx[(size_t)j * m + k]; }
+      w->qxx[(size_t)j * nx + i] += a;
+    }
+    for (int j = 0; j < nx; ++j) for (int i = 0; i < nu; ++i) {
+      double a = 0.0;
+      for (int k = 0; k < m; ++k) { double l = rho * Ju[(size_t)i * m + k]; if (which == 1) l = l * act[k]; a += l * Jx[(size_t)j * m + k]; }
+      w->qux[(size_t)j * nu + i] += a;
+    }
+    for (int j = 0; j < nu; ++j) for (int i = 0; i < nu; ++i) {
+      double a = 0.0;
+      for (int k = 0; k < m; ++k) { double l = rho * Ju[(size_t)i * m + k]; if (which == 1) l = l * act[k]; a += l * Ju[(size_t)j * m + k]; }
+      w->quu[(size_t)j * nu + i] += a;
+    }
+  }
+}
+
+/* multiplier and penalty updates after the line search, ilqr.hpp:236-260 */
+static void al_update(mas_ilqr* s, const mas_ocp* o, const double* X, const double* U) {
+  const int T = o->horizon_steps, nx = o->state_dim, nu = o->control_dim;
+  const int me = o->equality_constraints ? o->eq_dim : 0, mi = o->inequality_constraints ? o->ineq_dim : 0;
+  double eqv = 0.0, inv = 0.0, r[16];
+  for (int t = 0; t < T; ++t) {
+    if (me > 0) {
+      o->equality_constraints(o, X + (size_t)t * nx, U + (size_t)t * nu, r);
+      double sq = 0.0;
+      for (int k = 0; k < me; ++k) { s->eq_multipliers[(size_t)t * me + k] += s->penalty_parameter * r[k]; sq += r[k] * r[k]; }
+      eqv += sq;
+    }
+    if (mi > 0) {
+      o->inequality_constraints(o, X + (size_t)t * nx, U + (size_t)t * nu, r);
+      double sq = 0.0;
+      for (int k = 0; k < mi; ++k) {
+        const double positive = r[k] > 0.0 ? r[k] : 0.0;
+        const double v = s->ineq_multipliers[(size_t)t * mi + k] + s->penalty_parameter * positive;
+        s->ineq_multipliers[(size_t)t * mi + k] = v > 0.0 ? v : 0.0;
+        sq += positive * positive;
+      }
+      inv += sq;
+    }
+  }
+  s->last_eq_violation = sqrt(eqv); s->last_ineq_violation = sqrt(inv);
+  if (s->last_eq_violation > s->constraint_tolerance || s->last_ineq_violation > s->constraint_tolerance)
+    s->penalty_parameter *= s->penalty_increase;
+}
+
+/* iLQR::solve, ilqr.hpp:58-273.  Without constraint functions (every shipped example) merit == objective
+ * (ilqr.hpp:379-407) and the multiplier/penalty updates are no-ops. */
 void mas_ilqr_solve(mas_ilqr* s, mas_ocp* o) {
   const double start = now_ms();
   const int T = o->horizon_steps, nx = o->state_dim, nu = o->control_dim;
@@ -566,9 +710,12 @@ void mas_ilqr_solve(mas_ilqr* s, mas_ocp* o) {
   s->iterations = 0; s->exit_reason = MAS_EXIT_MAX_ITER; s->reg_events = 0; s->trials = 0;
   memset(s->alpha_hist, 0, sizeof(s->alpha_hist));
 
+  const int has_al = (o->equality_constraints && o->eq_dim > 0) || (o->inequality_constraints && o->ineq_dim > 0);
+  al_resize(s, T, o->equality_constraints ? o->eq_dim : 0, o->inequality_constraints ? o->ineq_dim : 0);
+  s->last_eq_violation = s->last_ineq_violation = 0.0;
   mas_integrate_horizon(o, o->initial_state, u, dt, x);      /* :75 warm start = best_controls */
   o->best_cost = mas_ocp_objective(o, x, u);                 /* :76 */
-  double current_merit = mas_ocp_objective(o, x, u);         /* :78 */
+  double current_merit = mas_ilqr_compute_merit(s, o, x, u); /* :78 */
   if (s->debug) printf("iLQR initial cost=%.17g merit=%.17g\n", o->best_cost, current_merit);
 
   for (int iter = 0; iter < s->max_iterations; ++iter) {
@@ -581,6 +728,7 @@ void mas_ilqr_solve(mas_ilqr* s, mas_ocp* o) {
     for (int t = T - 1; t >= 0; --t) {                       /* :104-193 */
       linearise_step(o, x + (size_t)t * nx, u + (size_t)t * nu, (size_t)t, &w);
       assemble_q(&w, vx, vxx);
+      if (has_al) al_terms(s, o, x + (size_t)t * nx, u + (size_t)t * nu, t, &w);
       int r = llt_ladder(&w);
       if (r < 0) { reg_fail = 1; break; }
       s->reg_events += r;
@@ -607,7 +755,7 @@ void mas_ilqr_solve(mas_ilqr* s, mas_ocp* o) {
         mas_integrate_rk4(o, xt, ut, dt, x_trial + (size_t)(t + 1) * nx);
       }
       ++s->trials;
-      const double trial_merit = mas_ocp_objective(o, x_trial, u_trial);
+      const double trial_merit = mas_ilqr_compute_merit(s, o, x_trial, u_trial);
       if (trial_merit < best_merit) {
         best_merit = trial_merit;
         memcpy(best_x, x_trial, sizeof(double) * nX); memcpy(best_u, u_trial, sizeof(double) * nU);
@@ -621,13 +769,15 @@ void mas_ilqr_solve(mas_ilqr* s, mas_ocp* o) {
     memcpy(x, best_x, sizeof(double) * nX); memcpy(u, best_u, sizeof(double) * nU);
     o->best_cost = mas_ocp_objective(o, x, u);
     current_merit = best_merit;
+    if (has_al) al_update(s, o, x, u);                        /* :236-260; current_merit is NOT recomputed */
     if (iter < s->trace_cap) {
       if (s->trace_cost) s->trace_cost[iter] = o->best_cost;
       if (s->trace_alpha) s->trace_alpha[iter] = accepted_j < 10 ? ldexp(1.0, -accepted_j) : 0.0;
     }
     if (s->debug)
       printf("iLQR iter %d: cost=%.17g merit=%.17g d_merit=%.17g\n", iter, o->best_cost, current_merit, improvement);
-    if (improvement < s->tolerance) { s->exit_reason = MAS_EXIT_CONVERGED; break; }   /* :269-271 */
+    if (improvement < s->tolerance && s->last_eq_violation < s->constraint_tolerance &&
+        s->last_ineq_violation < s->constraint_tolerance) { s->exit_reason = MAS_EXIT_CONVERGED; break; }   /* :269-271 */
   }
 }
 
@@ -645,9 +795,16 @@ static double collect_total(mas_ocp** ocps, int n) {   /* collect_solution, nash
   double c = 0.0; for (int i = 0; i < n; ++i) c += ocps[i]->best_cost; return c;
 }
 
+static double g_al_params[4] = {10.0, 5.0, 1e-4, 1e-6};
+void mas_oracle_set_al_params(double penalty, double penalty_increase, double constraint_tolerance, double inequality_activation_tolerance) {
+  g_al_params[0] = penalty; g_al_params[1] = penalty_increase; g_al_params[2] = constraint_tolerance; g_al_params[3] = inequality_activation_tolerance;
+}
 static mas_ilqr* make_solvers(int n, int max_iterations, double tolerance, double max_ms) {
   mas_ilqr* sv = (mas_ilqr*)calloc((size_t)n, sizeof(mas_ilqr));   /* nash.hpp:78-84: fresh solver per agent */
-  for (int i = 0; i < n; ++i) { mas_ilqr_init(&sv[i]); mas_ilqr_set_params(&sv[i], max_iterations, tolerance, max_ms, 0); }
+  for (int i = 0; i < n; ++i) {
+    mas_ilqr_init(&sv[i]); mas_ilqr_set_params(&sv[i], max_iterations, tolerance, max_ms, 0);
+    mas_ilqr_set_al_params(&sv[i], g_al_params[0], g_al_params[1], g_al_params[2], g_al_params[3]);
+  }
   return sv;
 }
 static void free_solvers(mas_ilqr* sv, int n) { for (int i = 0; i < n; ++i) mas_ilqr_free(&sv[i]); free(sv); }
@@ -1077,6 +1234,15 @@ static double b6_stage(const mas_ocp* o, const double* s, const double* c, size_
   return p[2] * dist * dist + p[3] * se * se + p[4] * delta * delta + p[5] * a * a + p[7] * c[0] * c[0] + p[7] * c[1] * c[1];
 }
 
+/* --- single track with function constraints: THIS REPO'S OWN test workload for the augmented-Lagrangian
+ * branch (no shipped reference example sets a constraint function).  Dynamics, cost and bounds of the
+ * single-track workload plus
+ *   equality    h(x,u) = [ delta - p[9] * a ]                (steering coupled to acceleration)
+ *   inequality  g(x,u) = [ v - p[8] ,  -v ]                  (speed limit, no reversing)
+ * params: single-track's [0..6], [8] v_max, [9] coupling */
+static void stl_eq(const mas_ocp* o, const double* x, const double* u, double* out) { (void)x; out[0] = u[0] - o->params[9] * u[1]; }
+static void stl_ineq(const mas_ocp* o, const double* x, const double* u, double* out) { (void)u; out[0] = x[3] - o->params[8]; out[1] = -x[3]; }
+
 int mas_model_dims(int model_id, int* nx, int* nu, int* n_params) {
   int a = 0, b = 0, c = 0;
   switch (model_id) {
@@ -1085,6 +1251,7 @@ int mas_model_dims(int model_id, int* nx, int* nu, int* n_params) {
     case MAS_MODEL_PENDULUM: a = 2; b = 1; c = 1; break;
     case MAS_MODEL_SINGLE_TRACK_LANE: a = 4; b = 2; c = 7; break;
     case MAS_MODEL_BICYCLE6: a = 6; b = 2; c = 8; break;
+    case MAS_MODEL_SINGLE_TRACK_LIMITED: a = 4; b = 2; c = 10; break;
     default: return -1;
   }
   if (nx) *nx = a;
@@ -1103,6 +1270,8 @@ void mas_model_default_params(int model_id, int T, double* p) {
       p[0] = 1.0; p[1] = 10.0; p[2] = 1.0; p[3] = 0.1; p[4] = 0.1; p[6] = 2.5; break;
     case MAS_MODEL_BICYCLE6:
       p[0] = 20.0; p[1] = 5.0; p[2] = 1.0; p[3] = 1.0; p[4] = 0.001; p[5] = 0.001; p[6] = 2.5; p[7] = 0.001; break;
+    case MAS_MODEL_SINGLE_TRACK_LIMITED:
+      p[0] = 20.0; p[1] = 5.0; p[2] = 1.0; p[3] = 1.0; p[4] = 0.001; p[5] = 0.001; p[6] = 2.5; p[8] = 4.5; p[9] = 0.1; break;
     default: break;
   }
 }
@@ -1143,6 +1312,13 @@ mas_ocp* mas_model_make_ocp(int model_id, int T, double dt, const double* x0, co
     } break;
     case MAS_MODEL_BICYCLE6: {
       o->dynamics = b6_dynamics; o->stage_cost = b6_stage;
+      const double lb[2] = {-0.5, -0.5}, ub[2] = {0.5, 0.5};
+      mas_ocp_set_input_bounds(o, lb, ub);
+    } break;
+    case MAS_MODEL_SINGLE_TRACK_LIMITED: {
+      o->dynamics = st_dynamics; o->stage_cost = st_stage;
+      o->equality_constraints = stl_eq; o->eq_dim = 1;
+      o->inequality_constraints = stl_ineq; o->ineq_dim = 2;
       const double lb[2] = {-0.5, -0.5}, ub[2] = {0.5, 0.5};
       mas_ocp_set_input_bounds(o, lb, ub);
     } break;

@@ -72,6 +72,15 @@ typedef struct mas_ocp {
   mas_x_mat_fn   terminal_cost_gradient;     /* nx    */
   mas_x_mat_fn   terminal_cost_hessian;      /* nx*nx */
 
+  /* function constraints (ocp.hpp:61-68): h(x,u) = 0, g(x,u) <= 0; NULL = none.  *_dim is what the
+   * reference obtains by evaluating the function once (ilqr.hpp:318-323).  Jacobian hooks: NULL => FD
+   * (ocp.hpp:137-171, finite_differences.hpp:289-345); column-major m x nx / m x nu. */
+  void (*equality_constraints)(const struct mas_ocp*, const double* x, const double* u, double* out);
+  void (*inequality_constraints)(const struct mas_ocp*, const double* x, const double* u, double* out);
+  int  eq_dim, ineq_dim;
+  mas_xu_mat_fn equality_constraints_state_jacobian, equality_constraints_control_jacobian;
+  mas_xu_mat_fn inequality_constraints_state_jacobian, inequality_constraints_control_jacobian;
+
   size_t id;
   int    model_id;       /* registry id, 0 for ad-hoc callback problems */
   double params[16];     /* model constants (meaning per model)          */
@@ -119,6 +128,16 @@ typedef struct mas_ilqr {
   double tolerance;
   double max_ms;
   int    debug;
+  /* augmented-Lagrangian state, ilqr.hpp:31-36,415-421: persists across solve() calls like the members of
+   * an iLQR object (multipliers are re-sized, not reset, by resize_buffers :331-338,354-362) */
+  double penalty_parameter;                 /* 10.0 */
+  double penalty_increase;                  /* 5.0  */
+  double constraint_tolerance;              /* 1e-4 */
+  double inequality_activation_tolerance;   /* 1e-6 */
+  int    mult_T, mult_eq_dim, mult_ineq_dim;
+  double* eq_multipliers;                   /* [T][eq_dim]   */
+  double* ineq_multipliers;                 /* [T][ineq_dim] */
+  double last_eq_violation, last_ineq_violation;
   /* statistics of the most recent solve (extension; reference exposes none) */
   int    iterations;        /* loop bodies executed                     */
   int    exit_reason;
@@ -139,7 +158,12 @@ void mas_ilqr_free(mas_ilqr*);
 /* set_params (ilqr.hpp:39-55): the three keys are required by the reference
  * (params.at throws); here they are plain arguments. */
 void mas_ilqr_set_params(mas_ilqr*, int max_iterations, double tolerance, double max_ms, int debug);
-void mas_ilqr_solve(mas_ilqr*, mas_ocp*);      /* ilqr.hpp:58-273 (no constraint functions) */
+void mas_ilqr_set_al_params(mas_ilqr*, double penalty, double penalty_increase, double constraint_tolerance,
+                            double inequality_activation_tolerance);   /* optional keys of ilqr.hpp:47-54 */
+void mas_ilqr_solve(mas_ilqr*, mas_ocp*);      /* ilqr.hpp:58-273 incl. the augmented-Lagrangian branch */
+double mas_ilqr_compute_merit(const mas_ilqr*, const mas_ocp*, const double* X, const double* U);   /* ilqr.hpp:379-407 */
+void mas_fd_constraints_state_jacobian(const mas_ocp*, int which /*0 eq, 1 ineq*/, const double* x, const double* u, double* J);   /* finite_differences.hpp:289-316 */
+void mas_fd_constraints_control_jacobian(const mas_ocp*, int which, const double* x, const double* u, double* J);                  /* :318-345 */
 
 /* one backward pass on a given trajectory; exposed so tests can compare the
  * linearisation + Riccati outputs of the HIP kernels stage by stage.
@@ -186,7 +210,9 @@ enum {
   MAS_MODEL_LQR_IDENTITY      = 2, /* examples/multi_agent_lqr.cpp:21-76   */
   MAS_MODEL_PENDULUM          = 3, /* examples/pendulum_swing_up.cpp:29-117 + models/pendulum_model.hpp:8-20 */
   MAS_MODEL_SINGLE_TRACK_LANE = 4, /* examples/single_track_ocp.cpp:14-116 (analytic derivs, FD cross term)  */
-  MAS_MODEL_BICYCLE6          = 5  /* this repo's own 6-state model (no reference counterpart)                */
+  MAS_MODEL_BICYCLE6          = 5, /* this repo's own 6-state model (no reference counterpart)                */
+  MAS_MODEL_SINGLE_TRACK_LIMITED = 6 /* this repo's own: single track + function constraints (speed limit, v >= 0,
+                                        steering/acceleration coupling) to exercise the augmented-Lagrangian branch */
 };
 
 /* Build an initialised OCP of a registered model.  x0: nx values.  U0: NULL => zeros.
@@ -206,6 +232,8 @@ double mas_oracle_solve_batch(int model_id, const double* params, int N, int T, 
                               int strategy, int max_outer, int max_iterations, double tolerance, double max_ms,
                               int threads, mas_strategy_stats* stats);
 int mas_oracle_max_threads(void);
+/* AL parameters given to every solver the strategy drivers create (defaults 10, 5, 1e-4, 1e-6) */
+void mas_oracle_set_al_params(double penalty, double penalty_increase, double constraint_tolerance, double inequality_activation_tolerance);
 /* 0 = platform libm (faithful to a glibc-linked reference binary), 1 = include/mas_dettrig.h */
 void mas_oracle_set_trig_mode(int mode);
 int  mas_oracle_get_trig_mode(void);

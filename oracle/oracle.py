@@ -21,6 +21,7 @@ MODEL_LQR_IDENTITY = 2
 MODEL_PENDULUM = 3
 MODEL_SINGLE_TRACK_LANE = 4
 MODEL_BICYCLE6 = 5
+MODEL_SINGLE_TRACK_LIMITED = 6
 
 STRATEGY = {"sequential": 0, "trustregion": 1, "linesearch": 2, "centralized_dense": 3,
             "centralized": 4, "single": 5}
@@ -59,6 +60,7 @@ def lib() -> C.CDLL:
         _lib.mas_oracle_max_threads.restype = C.c_int
         _lib.mas_oracle_set_trig_mode.argtypes = [C.c_int]
         _lib.mas_oracle_get_trig_mode.restype = C.c_int
+        _lib.mas_oracle_set_al_params.argtypes = [C.c_double] * 4
         for name in ("mas_ref_case_initialize", "mas_ref_case_update_initial", "mas_ref_case_global",
                      "mas_ref_case_fd_gradient"):
             getattr(_lib, name).argtypes = [d]
@@ -99,6 +101,11 @@ def set_trig_mode(mode: str) -> None:
 
 def get_trig_mode() -> str:
     return "det" if lib().mas_oracle_get_trig_mode() else "libm"
+
+
+def set_al_params(penalty=10.0, penalty_increase=5.0, constraint_tolerance=1e-4, inequality_activation_tolerance=1e-6) -> None:
+    """optional iLQR keys penalty / penalty_increase / constraint_tolerance / inequality_activation_tolerance (ilqr.hpp:47-54)"""
+    lib().mas_oracle_set_al_params(penalty, penalty_increase, constraint_tolerance, inequality_activation_tolerance)
 
 
 def max_threads() -> int:

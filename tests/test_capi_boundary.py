@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(product_lib):
 
 def test_model_registry_dims(product_lib):
     nx, nu = C.c_int(), C.c_int()
-    expected = {1: (4, 2), 2: (4, 4), 3: (2, 1), 4: (4, 2), 5: (6, 2)}
+    expected = {1: (4, 2), 2: (4, 4), 3: (2, 1), 4: (4, 2), 5: (6, 2), 6: (4, 2)}
     for mid, dims in expected.items():
         assert product_lib.mas_hip_model_dims(mid, C.byref(nx), C.byref(nu)) == 0
         assert (nx.value, nu.value) == dims

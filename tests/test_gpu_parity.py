@@ -197,3 +197,12 @@ def test_device_pointer_interface_with_torch(gpu_lib, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(X_out.cpu().numpy(), host["X"])
     assert np.array_equal(c_out.cpu().numpy(), host["cost"])
+
+
+@pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 3), ("trustregion", 3)])
+def test_constrained_single_track_augmented_lagrangian(gpu_lib, oracle, strategy, outer):
+    """augmented-Lagrangian branch (ilqr.hpp:121-170,236-260,379-407) on this repository's constrained workload"""
+    x0 = oracle.single_track_x0(70)
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, 30, 0.5, strategy, max_outer=outer)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, 30, 0.5, strategy=strategy, max_outer=outer)
+    _same(e, o)
