@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for a single rank (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -170,7 +171,7 @@ def main():
     device = local_rank % torch.cuda.device_count()      # one rank per GPU (several per GPU only in the gloo rehearsal)
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -53,14 +53,10 @@ struct Backend {
   void zero(void* d, size_t n) { std::memset(d, 0, n); }
   void sync() {}
   void resolve_profile() {}
-  // sub-batch streams (no-ops here: the emulation runs everything in program order)
+  // events (no-ops here: the emulation runs everything in program order)
   struct Event {};
-  Stream make_stream() { return nullptr; }
-  void drop_stream(Stream) {}
   Event make_event() { return Event{}; }
   void drop_event(Event) {}
-  void use(Stream) {}
-  void use_main() {}
   void record(Event&) {}
   void wait(Event&) {}
   void d2h_async(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
@@ -138,7 +134,7 @@ __global__ void __launch_bounds__(MAXT) mas_kernel_group(const F f, int n) {
 
 struct Backend {
   Stream stream = nullptr;       // the handle's main stream
-  Stream cur = nullptr;          // stream the next launch / async copy goes to (main or a sub-batch stream)
+  Stream cur = nullptr;          // stream every launch / async copy goes to (== stream)
   bool own_stream = false;
   int device = 0;
   bool profiling = false;
@@ -159,15 +155,10 @@ struct Backend {
     else { MAS_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
     cur = stream;
   }
-  // sub-batch streams: independent agent ranges iterate concurrently so that their latency-bound
-  // kernels overlap on the chip
+  // completion events of the iteration rounds (the host runs one round ahead of the device)
   using Event = hipEvent_t;
-  Stream make_stream() { Stream s; MAS_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
-  void drop_stream(Stream s) { if (s) (void)hipStreamDestroy(s); }
   Event make_event() { Event e; MAS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); return e; }
   void drop_event(Event e) { (void)hipEventDestroy(e); }
-  void use(Stream s) { cur = s; }
-  void use_main() { cur = stream; }
   void record(Event& e) { MAS_HIP_CHECK(hipEventRecord(e, cur)); }
   void wait(Event& e) { MAS_HIP_CHECK(hipEventSynchronize(e)); }
   void d2h_async(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, cur)); }
