@@ -17,6 +17,8 @@
 // differences chaotically (include/mas_dettrig.h), so a fused product would break parity.
 #pragma once
 
+#include <type_traits>
+
 #include "mas_bodies.hpp"
 
 namespace mas {
@@ -62,22 +64,28 @@ __global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, c
   double* st = stage[w];
   // the 64 tiles of this wavefront: 4 (5, 7 ...) chunk runs of 64*cw doubles each, contiguous and 64-B aligned
   double* block = D + (static_cast<size_t>(t) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
-  const bool full = mask == ~0ull;                                  // wave-uniform
-  MAS_UNROLL for (int c0 = 0; c0 < ND; c0 += CH) {
-    const int cw = (ND - c0 < CH) ? (ND - c0) : CH;                // compile-time after unrolling
-    double* run = block + static_cast<size_t>(c0) * 64;
-    __builtin_amdgcn_wave_barrier();
-    MAS_UNROLL for (int e = 0; e < CH; ++e) { if (e < cw) st[lane * PITCH + e] = Dl[c0 + e]; }
-    __builtin_amdgcn_wave_barrier();                                // LDS ops of one wave complete in order
-    MAS_UNROLL for (int k = 0; k < CH; ++k) {
-      if (k < cw) {
-        const int idx = k * 64 + lane;                              // linear index into the run: [agent][cw]
-        const int ag = idx / cw, e = idx - ag * cw;
-        const double v = st[ag * PITCH + e];
-        if (full || ((mask >> ag) & 1ull)) run[idx] = v;            // 64 lanes -> 512 contiguous bytes
+  // two copies of the store loop, chosen once per wavefront: all 64 agents active (plain stores) or not
+  // (each store predicated on its tile's agent)
+  auto flush = [&](auto masked_tag) {
+    constexpr bool kMasked = decltype(masked_tag)::value;
+    MAS_UNROLL for (int c0 = 0; c0 < ND; c0 += CH) {
+      const int cw = (ND - c0 < CH) ? (ND - c0) : CH;              // compile-time after unrolling
+      double* run = block + static_cast<size_t>(c0) * 64;
+      __builtin_amdgcn_wave_barrier();
+      MAS_UNROLL for (int e = 0; e < CH; ++e) { if (e < cw) st[lane * PITCH + e] = Dl[c0 + e]; }
+      __builtin_amdgcn_wave_barrier();                              // LDS ops of one wave complete in order
+      MAS_UNROLL for (int k = 0; k < CH; ++k) {
+        if (k < cw) {
+          const int idx = k * 64 + lane;                            // linear index into the run: [agent][cw]
+          const int ag = idx / cw, e = idx - ag * cw;
+          const double v = st[ag * PITCH + e];
+          if constexpr (kMasked) { if ((mask >> ag) & 1ull) run[idx] = v; }
+          else run[idx] = v;                                        // 64 lanes -> 512 contiguous bytes
+        }
       }
     }
-  }
+  };
+  if (mask == ~0ull) flush(std::false_type{}); else flush(std::true_type{});
 }
 
 // ---------------------------------------------------------------- backward, 16 lanes/agent --

@@ -309,6 +309,10 @@ class SolverImpl final : public SolverBase {
       }
       if (hi_t == 0ull) continue;
       ks.launches++; ks.total_ms += static_cast<double>(hi_t - lo_t) * 1e-5; ks.algorithmic_bytes += sl.bytes;
+      if (sl.bytes >= sweep_bytes() * static_cast<double>(d.N)) {   // launches with every agent active: the kernel at its design point
+        KernelStat& kf = be.stats["sweep_inkernel_full"];
+        kf.launches++; kf.total_ms += static_cast<double>(hi_t - lo_t) * 1e-5; kf.algorithmic_bytes += sl.bytes;
+      }
     }
     stamp_used = 0; stamp_launches.clear();
 #endif
