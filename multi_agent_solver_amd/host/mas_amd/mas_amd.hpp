@@ -241,34 +241,54 @@ class MultiAgentProblem {                          // multi_agent_problem.hpp:24
 
 namespace detail {
 
-// The GPU path batches the id-sorted block list into ONE handle; that needs agents of one model, horizon,
-// step and bound set (true for every reference example).
+// The strategies that couple agents (line search, centralised) batch the id-sorted block list into ONE
+// handle; that needs agents of one model, horizon, step and bound set (true for every reference example).
+inline bool same_batch(const OCP& a, const OCP& b);
 inline void require_homogeneous(const MultiAgentProblem& p) {
   if (p.blocks.empty()) throw std::invalid_argument("MultiAgentProblem has no agents");
   const OCP& f = *p.blocks.front().agent->ocp;
-  for (const auto& b : p.blocks) {
-    const OCP& o = *b.agent->ocp;
-    if (!(o.model == f.model) || o.horizon_steps != f.horizon_steps || o.dt != f.dt || o.state_dim != f.state_dim ||
-        o.control_dim != f.control_dim || o.input_lower_bounds != f.input_lower_bounds || o.input_upper_bounds != f.input_upper_bounds)
-      throw std::invalid_argument("the HIP iLQR path batches agents of one model / horizon / dt / bounds");
-  }
+  for (const auto& b : p.blocks)
+    if (!same_batch(*b.agent->ocp, f))
+      throw std::invalid_argument("this strategy couples all agents: the HIP iLQR path needs agents of one model / horizon / dt / bounds");
 }
 
+// one homogeneous group of blocks (indices into problem.blocks) resident in one handle
 struct BatchedProblem {
   std::unique_ptr<Batch> batch;
+  std::vector<int> members;
   int N = 0, T = 0, nx = 0, nu = 0;
 };
 
-inline BatchedProblem upload(MultiAgentProblem& problem, const SolverParams& params, bool warm_from_best) {
-  require_homogeneous(problem);
-  const OCP& f = *problem.blocks.front().agent->ocp;
+inline bool same_batch(const OCP& a, const OCP& b) {
+  return a.model == b.model && a.horizon_steps == b.horizon_steps && a.dt == b.dt && a.state_dim == b.state_dim &&
+         a.control_dim == b.control_dim && a.input_lower_bounds == b.input_lower_bounds && a.input_upper_bounds == b.input_upper_bounds;
+}
+
+// Agents of one model / horizon / dt / bound set share a handle.  The per-agent strategies (sequential,
+// trust-region) treat agents independently, so a mixed problem is simply split into several batches; the
+// strategies that couple agents through the total cost (line search) or a stacked solve (centralised) need
+// a single batch.
+inline std::vector<std::vector<int>> group_blocks(const MultiAgentProblem& p) {
+  std::vector<std::vector<int>> groups;
+  for (int i = 0; i < static_cast<int>(p.blocks.size()); ++i) {
+    bool placed = false;
+    for (auto& g : groups)
+      if (same_batch(*p.blocks[g.front()].agent->ocp, *p.blocks[i].agent->ocp)) { g.push_back(i); placed = true; break; }
+    if (!placed) groups.push_back({i});
+  }
+  return groups;
+}
+
+inline BatchedProblem upload(MultiAgentProblem& problem, const std::vector<int>& members, const SolverParams& params, bool warm_from_best) {
+  const OCP& f = *problem.blocks[members.front()].agent->ocp;
   BatchedProblem bp;
-  bp.N = static_cast<int>(problem.blocks.size()); bp.T = f.horizon_steps; bp.nx = f.state_dim; bp.nu = f.control_dim;
+  bp.members = members;
+  bp.N = static_cast<int>(members.size()); bp.T = f.horizon_steps; bp.nx = f.state_dim; bp.nu = f.control_dim;
   bp.batch = std::make_unique<Batch>(f.model, bp.N, bp.T, f.dt, f.input_lower_bounds, f.input_upper_bounds);
   bp.batch->set_params(params);
   std::vector<double> x0(static_cast<size_t>(bp.N) * bp.nx), U(static_cast<size_t>(bp.N) * bp.T * bp.nu, 0.0);
   for (int i = 0; i < bp.N; ++i) {
-    const OCP& o = *problem.blocks[i].agent->ocp;
+    const OCP& o = *problem.blocks[members[i]].agent->ocp;
     std::copy(o.initial_state.begin(), o.initial_state.end(), x0.begin() + static_cast<size_t>(i) * bp.nx);
     const ControlTrajectory& src = warm_from_best ? o.best_controls : o.initial_controls;
     if (src.rows() == bp.nu && src.cols() == bp.T) std::copy(src.data.begin(), src.data.end(), U.begin() + static_cast<size_t>(i) * bp.T * bp.nu);
@@ -279,26 +299,62 @@ inline BatchedProblem upload(MultiAgentProblem& problem, const SolverParams& par
   return bp;
 }
 
-// collect_solution (nash.hpp:23-37) + write-back into every OCP
-inline Solution download(MultiAgentProblem& problem, BatchedProblem& bp, bool publish_initial) {
+inline BatchedProblem upload(MultiAgentProblem& problem, const SolverParams& params, bool warm_from_best) {
+  require_homogeneous(problem);
+  std::vector<int> all(problem.blocks.size());
+  for (size_t i = 0; i < all.size(); ++i) all[i] = static_cast<int>(i);
+  return upload(problem, all, params, warm_from_best);
+}
+
+// write the results of one batch back into its OCPs
+inline void download_into(MultiAgentProblem& problem, BatchedProblem& bp, bool publish_initial, std::vector<int>& iterations) {
   const size_t nX = static_cast<size_t>(bp.nx) * (bp.T + 1), nU = static_cast<size_t>(bp.nu) * bp.T;
   std::vector<double> X(nX * bp.N), U(nU * bp.N), cost(bp.N);
   std::vector<int32_t> it(bp.N), ex(bp.N);
   bp.batch->check(mas_hip_get_solution_host(bp.batch->get(), X.data(), U.data(), cost.data(), it.data(), ex.data()), "get_solution");
-  Solution sol;
   for (int i = 0; i < bp.N; ++i) {
-    OCP& o = *problem.blocks[i].agent->ocp;
+    OCP& o = *problem.blocks[bp.members[i]].agent->ocp;
     o.best_states = StateTrajectory(bp.nx, bp.T + 1);
     o.best_controls = ControlTrajectory(bp.nu, bp.T);
     std::copy(X.begin() + nX * i, X.begin() + nX * (i + 1), o.best_states.data.begin());
     std::copy(U.begin() + nU * i, U.begin() + nU * (i + 1), o.best_controls.data.begin());
     o.best_cost = cost[i];
     if (publish_initial) o.update_initial_with_best();   // nash.hpp:66-71
-    sol.states.push_back(o.best_states); sol.controls.push_back(o.best_controls); sol.costs.push_back(o.best_cost);
-    sol.iterations.push_back(it[i]);
+    iterations[bp.members[i]] = it[i];
   }
-  bp.batch->check(mas_hip_total_cost(bp.batch->get(), &sol.total_cost), "total_cost");
+}
+
+// collect_solution (nash.hpp:23-37): blocks in id order, total = sum of best_cost in that order
+inline Solution collect_solution(MultiAgentProblem& problem, const std::vector<int>& iterations) {
+  Solution sol;
+  for (size_t i = 0; i < problem.blocks.size(); ++i) {
+    const OCP& o = *problem.blocks[i].agent->ocp;
+    sol.states.push_back(o.best_states); sol.controls.push_back(o.best_controls); sol.costs.push_back(o.best_cost);
+    sol.total_cost += o.best_cost;
+  }
+  sol.iterations = iterations;
   return sol;
+}
+
+inline Solution download(MultiAgentProblem& problem, BatchedProblem& bp, bool publish_initial) {
+  std::vector<int> iterations(problem.blocks.size(), 0);
+  download_into(problem, bp, publish_initial, iterations);
+  Solution sol = collect_solution(problem, iterations);
+  bp.batch->check(mas_hip_total_cost(bp.batch->get(), &sol.total_cost), "total_cost");   // centralised: the stacked merit
+  return sol;
+}
+
+// per-agent strategies over a possibly mixed agent list: one batch per homogeneous group
+template <class Run>
+inline Solution run_grouped(MultiAgentProblem& problem, const SolverParams& params, Run&& run) {
+  if (problem.blocks.empty()) throw std::invalid_argument("MultiAgentProblem has no agents");
+  std::vector<int> iterations(problem.blocks.size(), 0);
+  for (const auto& members : group_blocks(problem)) {
+    auto bp = upload(problem, members, params, true);
+    run(*bp.batch);
+    download_into(problem, bp, true, iterations);
+  }
+  return collect_solution(problem, iterations);
 }
 
 inline const SolverParams& params_of(const Solver& s) { return std::get<iLQR>(s).params(); }
@@ -340,9 +396,8 @@ struct SequentialNashStrategy {                    // strategies/nash.hpp:250-26
   SequentialNashStrategy(int outer, Solver s, SolverParams p) : max_outer(outer), solver_proto(std::move(s)), params(std::move(p)) {}
   Solution operator()(MultiAgentProblem& problem) {
     problem.compute_offsets();
-    auto bp = detail::upload(problem, params, true);
-    bp.batch->check(mas_hip_run_sequential(bp.batch->get(), max_outer), "run_sequential");
-    return detail::download(problem, bp, true);
+    const int outer = max_outer;
+    return detail::run_grouped(problem, params, [outer](detail::Batch& b) { b.check(mas_hip_run_sequential(b.get(), outer), "run_sequential"); });
   }
 };
 
@@ -362,9 +417,8 @@ struct TrustRegionNashStrategy {                   // strategies/nash.hpp:290-30
   TrustRegionNashStrategy(int outer, Solver s, SolverParams p) : max_outer(outer), solver_proto(std::move(s)), params(std::move(p)) {}
   Solution operator()(MultiAgentProblem& problem) {
     problem.compute_offsets();
-    auto bp = detail::upload(problem, params, true);
-    bp.batch->check(mas_hip_run_trust_region(bp.batch->get(), max_outer), "run_trust_region");
-    return detail::download(problem, bp, true);
+    const int outer = max_outer;
+    return detail::run_grouped(problem, params, [outer](detail::Batch& b) { b.check(mas_hip_run_trust_region(b.get(), outer), "run_trust_region"); });
   }
 };
 

@@ -89,3 +89,28 @@ def test_lqr_and_pendulum_examples(exe_dir, oracle):
     o = oracle.solve_batch(oracle.MODEL_PENDULUM, x0, U0, 50, 0.05, strategy="single", max_iterations=1000, tolerance=1e-4)
     assert _result_line(r.stdout).group(4) == f"{o['cost'][0]:.6f}"
     assert "pendulum_states\ntime,x0,x1\n" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", ["sequential", "trustregion"])
+def test_mixed_models_are_split_into_homogeneous_batches(exe_dir, oracle, strategy):
+    """agents of different models in one MultiAgentProblem (allowed by the reference: every agent owns its OCP)"""
+    n, T = 7, 20
+    r = _run(exe_dir, "mixed_agents", "--agents", str(n), "--strategy", strategy, "--horizon", str(T), "--max-outer", "3")
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    got = {int(l.split()[1]): (int(l.split()[3]), float(l.split()[5]), int(l.split()[7])) for l in lines[1:]}
+    st_ids = [i for i in range(n) if i % 2 == 0]
+    x0 = oracle.single_track_x0(n)[st_ids]
+    o_st = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy=strategy, max_outer=3)
+    o_lq = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, oracle.lqr_x0(1), None, T, 0.1, strategy=strategy, max_outer=3)
+    total = 0.0
+    for i in range(n):
+        model, cost, iters = got[i]
+        if i % 2 == 0:
+            k = st_ids.index(i)
+            assert model == 1 and cost == o_st["cost"][k] and iters == o_st["iters"][k]
+        else:
+            assert model == 2 and cost == o_lq["cost"][0] and iters == o_lq["iters"][0]
+        total += cost
+    assert float(lines[0].split("cost=")[1]) == total
