@@ -206,3 +206,27 @@ def test_constrained_single_track_augmented_lagrangian(gpu_lib, oracle, strategy
     e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, 30, 0.5, strategy, max_outer=outer)
     o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, 30, 0.5, strategy=strategy, max_outer=outer)
     _same(e, o)
+
+
+def test_config5_bicycle6_shard_properties_and_sampled_parity(gpu_lib, oracle):
+    """BASELINE config 5 per-GPU shard: 8192 bicycle6 agents (this repository's own nx=6 model), H=200,
+    trust-region strategy, max_outer 10.  Properties on all agents + exact oracle parity on a sample."""
+    from multi_agent_solver_amd.batch import BatchSolver, bicycle6_x0
+    N, T, dt = 8192, 200, 0.25
+    x0 = bicycle6_x0(N)
+    with BatchSolver(oracle.MODEL_BICYCLE6, N, T, dt, lib=gpu_lib) as s:
+        s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+        s.set_initial_states(x0)
+        s.set_controls(None)
+        s.initialize_problem()
+        init = s.solution()
+        s.run_trust_region(10)
+        e = s.solution()
+        radii = s.trust_radii()
+    assert np.isfinite(e["cost"]).all() and (e["cost"] <= init["cost"]).all()      # accept only if the cost decreases (nash.hpp:228)
+    assert (np.abs(e["U"]) <= 0.5).all()
+    assert ((radii > 0) & np.isfinite(radii)).all()
+    sample = [0, 5, 4097, 8191]
+    o = oracle.solve_batch(oracle.MODEL_BICYCLE6, x0[sample], None, T, dt, strategy="trustregion")
+    assert np.array_equal(e["cost"][sample], o["cost"]) and np.array_equal(e["X"][sample], o["X"])
+    assert e["iters"][sample].tolist() == o["iters"].tolist()
