@@ -245,7 +245,7 @@ namespace detail {
 // handle; that needs agents of one model, horizon, step and bound set (true for every reference example).
 inline bool same_batch(const OCP& a, const OCP& b);
 inline void require_homogeneous(const MultiAgentProblem& p) {
-  if (p.blocks.empty()) throw std::invalid_argument("MultiAgentProblem has no agents");
+  if (p.blocks.empty()) return;
   const OCP& f = *p.blocks.front().agent->ocp;
   for (const auto& b : p.blocks)
     if (!same_batch(*b.agent->ocp, f))
@@ -347,7 +347,7 @@ inline Solution download(MultiAgentProblem& problem, BatchedProblem& bp, bool pu
 // per-agent strategies over a possibly mixed agent list: one batch per homogeneous group
 template <class Run>
 inline Solution run_grouped(MultiAgentProblem& problem, const SolverParams& params, Run&& run) {
-  if (problem.blocks.empty()) throw std::invalid_argument("MultiAgentProblem has no agents");
+  if (problem.blocks.empty()) return Solution{};      // nothing to solve: empty Solution, total_cost 0 (nash.hpp:23-37)
   std::vector<int> iterations(problem.blocks.size(), 0);
   for (const auto& members : group_blocks(problem)) {
     auto bp = upload(problem, members, params, true);
@@ -365,6 +365,7 @@ inline const SolverParams& params_of(const Solver& s) { return std::get<iLQR>(s)
 // examples/multi_agent_single_track.cpp:113-118)
 inline void initialize_agents(MultiAgentProblem& problem) {
   problem.compute_offsets();
+  if (problem.blocks.empty()) return;
   for (auto& b : problem.blocks) {
     OCP& o = *b.agent->ocp;
     if (o.initial_controls.rows() != o.control_dim || o.initial_controls.cols() != o.horizon_steps)
@@ -385,6 +386,7 @@ struct CentralizedStrategy {                       // strategies/centralized.hpp
   explicit CentralizedStrategy(Solver s) : solver(std::move(s)) {}
   Solution operator()(MultiAgentProblem& problem) {
     problem.compute_offsets();
+    if (problem.blocks.empty()) return Solution{};
     auto bp = detail::upload(problem, detail::params_of(solver), false);
     bp.batch->check(mas_hip_run_centralized(bp.batch->get()), "run_centralized");
     return detail::download(problem, bp, false);
@@ -406,6 +408,7 @@ struct LineSearchNashStrategy {                    // strategies/nash.hpp:270-28
   LineSearchNashStrategy(int outer, Solver s, SolverParams p) : max_outer(outer), solver_proto(std::move(s)), params(std::move(p)) {}
   Solution operator()(MultiAgentProblem& problem) {
     problem.compute_offsets();
+    if (problem.blocks.empty()) return Solution{};
     auto bp = detail::upload(problem, params, true);
     bp.batch->check(mas_hip_run_line_search(bp.batch->get(), max_outer), "run_line_search");
     return detail::download(problem, bp, true);

@@ -41,6 +41,13 @@ def test_cli_errors_match_the_reference(exe_dir, args, msg):
     assert "Use --help to see available options." in r.stderr
 
 
+def test_zero_agents_gives_an_empty_solution_like_the_reference(exe_dir):
+    # nothing to solve: the strategies return an empty Solution (total_cost 0) without touching the GPU
+    r = _run(exe_dir, "multi_agent_single_track", "--agents", "0", "--strategy", "sequential")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("solver=ilqr strategy=sequential agents=0 cost=0.000000 time_ms=")
+
+
 def test_no_gpu_is_a_loud_error_not_a_cpu_fallback(exe_dir, product_lib):
     if product_lib.mas_hip_device_count() > 0:
         pytest.skip("a GPU is visible")
