@@ -94,7 +94,7 @@ struct BackwardTileLayout {
   using L = DerivLayout<M>;
   static constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
   static constexpr int oD = 0, oV = oD + ND, oVx = oV + NX * NX, oAtV = oVx + NX, oBtV = oAtV + NX * NX, oQx = oBtV + NU * NX,
-                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oDummy = oQuu + NU * NU, kEnd = oDummy + 1;
+                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oDummy = oQuu + NU * NU, oNegZero = oDummy + 1, kEnd = oNegZero + 1;
   static constexpr int STRIDE = (kEnd % 32 == 0) ? kEnd + 2 : kEnd;     // keep agents on different LDS banks
 };
 
@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   if (!valid) {                                     // idle slot: finite operands (its lanes run the same code, results unused)
     for (int e = lane; e < TL::STRIDE; e += LPA) T[e] = 0.0;
   }
+  if (lane == 0) T[TL::oNegZero] = -0.0;            // additive identity that keeps every bit of the other operand (x + -0.0 == x)
   if (valid && lane == 0) {                         // terminal boundary condition, ilqr.hpp:92-102
     double xT[NX], vx[NX], vxx[NX * NX];
     MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = MAS_AT(X, d.T * NX + i, a);
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   int p1[R1], q1[R1], b1[R1], o1[R1];              // pass 1: out = [bias +] sum_k T[p+k] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R1; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, qa = 0, ba = -1, oa = TL::oDummy;
+    int pa = 0, qa = 0, ba = TL::oNegZero, oa = TL::oDummy;
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
     else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
     else if (w < NX * NX + NU * NX + NX) { const int i = w - NX * NX - NU * NX; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }
@@ -170,6 +171,13 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   };
   fetch(d.T - 1);
   long long regs = 0;
+  // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
+  // reference's `reg *= 10.0`) for the q < lane rungs it has to apply, -0.0 (adds nothing, changes no bit) after
+  double rung_add[LPA - 1];
+  {
+    double reg = 1e-6;
+    MAS_UNROLL for (int q = 0; q < LPA - 1; ++q) { rung_add[q] = (q < lane) ? reg : -0.0; reg *= 10.0; }
+  }
   // gain stores: uniform per-step base pointers + loop-invariant 32-bit byte offsets (row * Np + agent) * 8
   constexpr int RMX = (NX * NX + LPA - 1) / LPA;
   unsigned goff[NU], koff[RMX][NU];                  // k rows; this lane's gain column (rows i*NU + m) per round
@@ -195,8 +203,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       MAS_UNROLL for (int r = 0; r < R1; ++r) {
         double s = 0.0;
         MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p1[r] + k] * T[q1[r] + k];
-        const double bias = T[b1[r] < 0 ? 0 : b1[r]];
-        res[r] = (b1[r] < 0) ? s : bias + s;
+        res[r] = T[b1[r]] + s;                                        // items without a bias term add -0.0
       }
       MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // padding items write the tile's dummy slot
     }
@@ -225,13 +232,10 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       {
         double cur[NU * NU];
         MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = quu[i];
-        // reg_q = 1e-6 * 10^q by repeated multiplication, exactly the reference's `reg *= 10.0`; the
-        // additions stay sequential (floating-point addition is not associative) but are predicated
-        // straight-line code, no loop: lane r applies the first r of them
-        double reg = 1e-6;
+        // the additions stay sequential (floating-point addition is not associative): straight-line code
+        // over the lane's precomputed addends, lane r applying the first r of them
         MAS_UNROLL for (int q = 0; q < LPA - 1; ++q) {
-          if (q < lane) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg; }
-          reg *= 10.0;
+          MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += rung_add[q];
         }
         double reg_next = 0.0;                                         // this lane's next rung value, only needed past rung 15
         int base = 0, win = -1;
