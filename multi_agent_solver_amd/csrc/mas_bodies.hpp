@@ -215,6 +215,7 @@ struct ForwardBody {
     double c = 0.0;
     for (int t = 0; t < d.T; ++t) {
       if (t + 1 < d.T) { Xt += sX; Ut += sU; kt += sU; Kt += sK; }   // uniform
+      MAS_UNROLL for (int i = 0; i < NR; ++i) MAS_OPAQUE32(off[i]);
       MAS_UNROLL for (int i = 0; i < NX; ++i) xr_n[i] = ld_off(Xt, off[i]);
       MAS_UNROLL for (int i = 0; i < NU; ++i) ur_n[i] = ld_off(Ut, off[i]);
       MAS_UNROLL for (int i = 0; i < NU; ++i) k_n[i] = ld_off(kt, off[i]);

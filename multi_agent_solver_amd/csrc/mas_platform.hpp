@@ -17,3 +17,13 @@
 #define MAS_D __device__ __forceinline__
 #define MAS_UNROLL _Pragma("unroll")
 #endif
+
+// MAS_OPAQUE32(v): hides a loop-invariant 32-bit byte offset from the optimiser inside a loop.  Without it
+// LICM hoists the zero-extension to 64 bits out of the loop and instruction selection no longer sees
+// "uniform base + zext(32-bit lane offset)", so every access pays a v_lshl_add_u64 (and a hazard nop)
+// instead of using the scalar-base addressing form  global_load v, v_off32, s[base:base+1].
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAS_OPAQUE32(v) asm volatile("" : "+v"(v))
+#else
+#define MAS_OPAQUE32(v) ((void)0)
+#endif
