@@ -158,18 +158,25 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   }
 
   // software pipeline: the four tiles of step t-1 travel HBM -> registers while step t is computed.
-  // Per chunk the 4 tiles are 4*cw contiguous doubles (tile_offset); lane tid < 4*cw takes one of them.
+  // Per chunk the 4 tiles are 4*cw contiguous doubles (tile_offset); lane tid < 4*cw takes one of them.  No
+  // predication: a surplus lane of the short last chunk re-reads the chunk's last element and publishes it to
+  // its tile's dummy slot, so fetch and publish are NCH loads and NCH LDS writes with loop-invariant per-lane
+  // offsets and one uniform base pointer that steps back by Np*ND doubles per time step.
   constexpr int NCH = (ND + kTileChunk - 1) / kTileChunk;
   double pre[NCH];
-  auto fetch = [&](int t) {
-    const double* blockp = D + (static_cast<size_t>(t) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
-    MAS_UNROLL for (int c = 0; c < NCH; ++c) {
-      const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
-      const double* run = blockp + static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a0 % 64) * cw;
-      pre[c] = (tid < APW * cw) ? run[tid] : 0.0;
-    }
-  };
-  fetch(d.T - 1);
+  unsigned fetch_off[NCH]; int publish_at[NCH];
+  MAS_UNROLL for (int c = 0; c < NCH; ++c) {
+    const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
+    const bool mine = tid < APW * cw;
+    const int idx = mine ? tid : APW * cw - 1;
+    const int sl = idx / cw;
+    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a0 % 64) * cw + idx) * sizeof(double));
+    publish_at[c] = mine ? sl * TL::STRIDE + TL::oD + c * kTileChunk + (idx - sl * cw) : slot * TL::STRIDE + TL::oDummy;
+  }
+  const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
+  const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
+  auto fetch = [&]() { MAS_UNROLL for (int c = 0; c < NCH; ++c) pre[c] = ld_off(tiles_t, fetch_off[c]); };
+  fetch();
   long long regs = 0;
   // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
   // reference's `reg *= 10.0`) for the q < lane rungs it has to apply, -0.0 (adds nothing, changes no bit) after
@@ -190,11 +197,12 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
 
   for (int t = d.T - 1; t >= 0; --t, kff_t -= static_cast<size_t>(NU) * d.Np, Kfb_t -= static_cast<size_t>(NU) * NX * d.Np) {
-    MAS_UNROLL for (int c = 0; c < NCH; ++c) {
-      const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
-      if (tid < APW * cw) { const int sl = tid / cw; lds[sl * TL::STRIDE + TL::oD + c * kTileChunk + (tid - sl * cw)] = pre[c]; }
-    }
-    if (t > 0) fetch(t - 1);
+    MAS_UNROLL for (int c = 0; c < NCH; ++c) lds[publish_at[c]] = pre[c];
+    if (t > 0) tiles_t -= step_doubles;              // uniform; at t == 0 the (unused) prefetch re-reads step 0
+    MAS_UNROLL for (int c = 0; c < NCH; ++c) MAS_OPAQUE32(fetch_off[c]);
+    MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(goff[m]);
+    MAS_UNROLL for (int r = 0; r < RMX; ++r) { MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(koff[r][m]); }
+    fetch();
     __syncthreads();
 
     // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
