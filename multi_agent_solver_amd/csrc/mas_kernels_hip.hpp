@@ -245,20 +245,36 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int q = 0; q < LPA - 1; ++q) {
           MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += rung_add[q];
         }
-        double reg_next = 0.0;                                         // this lane's next rung value, only needed past rung 15
-        int base = 0, win = -1;
-        for (;;) {
+        // rungs 0..15 first, as straight-line code (three out of four steps need no regularisation at all and
+        // the rest settle within 15 rungs on every workload of this repository) ...
+        int win = -1;
+        {
           MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
-          const int ok = llt_compute<NU>(Lfac) == 0;
-          const unsigned long long okmask = __ballot(ok);
-          const unsigned field = static_cast<unsigned>(okmask >> (slot * LPA)) & 0xFFFFu;
-          if (win < 0 && field != 0u) win = base + __builtin_ctz(field);
-          if (win < 0 && base + LPA > kRegLadderMax) win = base + LPA - 1;     // guard, never reached (see kRegLadderMax)
-          if (__ballot(win < 0) == 0ull) break;                                // every agent of the wavefront is settled
-          if (win < 0) {                                                      // this agent goes on with rungs base+16 .. base+31
-            if (base == 0) { reg_next = 1e-6; for (int q = 0; q < lane; ++q) reg_next *= 10.0; }
-            for (int q = 0; q < LPA; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
-            base += LPA;
+          const int ok = llt_compute_straight<NU>(Lfac) == 0;
+          const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+          if (field != 0u) win = __builtin_ctz(field);
+        }
+        // ... and the general ladder only if some agent of the wavefront is still unsettled: its lanes go on
+        // with rungs base+16 .. base+31, and so on
+        if (__ballot(win < 0) != 0ull) {
+          double reg_next = 0.0;                                       // this lane's next rung value
+          int base = 0;
+          for (;;) {
+            if (win < 0 && base + LPA > kRegLadderMax) win = base + LPA - 1;   // guard, never reached (see kRegLadderMax)
+            if (__ballot(win < 0) == 0ull) break;                              // every agent of the wavefront is settled
+            if (win < 0) {
+              if (base == 0) { reg_next = 1e-6; for (int q = 0; q < lane; ++q) reg_next *= 10.0; }
+              for (int q = 0; q < LPA; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
+              base += LPA;
+            }
+            double Ltry[NU * NU];
+            MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Ltry[i] = cur[i];
+            const int ok = llt_compute<NU>(Ltry) == 0;
+            const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (win < 0) {
+              MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = Ltry[i];
+              if (field != 0u) win = base + __builtin_ctz(field);
+            }
           }
         }
         if (lane == (win & (LPA - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oAtV + i] = Lfac[i]; }   // oAtV is dead after pass 2

@@ -306,6 +306,31 @@ MAS_HD int llt_compute(double* Mx) {
   return fail;
 }
 
+// The same factorisation as straight-line code: every pivot is processed, a failed one only raises the flag.
+// When the result is 0 (success) every operation and value is the one llt_compute performs; after a failure the
+// contents of Mx are meaningless (sqrt of a negative pivot is NaN) and the caller must not use them.
+template <int N>
+MAS_HD int llt_compute_straight(double* Mx) {
+  int fail = 0;
+  MAS_UNROLL for (int k = 0; k < N; ++k) {
+    double x = Mx[k * N + k];
+    if (k > 0) {
+      double s = 0.0;
+      MAS_UNROLL for (int j = 0; j < k; ++j) s += Mx[j * N + k] * Mx[j * N + k];
+      x = Mx[k * N + k] - s;
+    }
+    fail |= (x <= 0.0) ? 1 : 0;
+    x = sqrt(x);
+    Mx[k * N + k] = x;
+    MAS_UNROLL for (int r = k + 1; r < N; ++r) {
+      double a = Mx[k * N + r];
+      MAS_UNROLL for (int j = 0; j < k; ++j) a += (-Mx[j * N + k]) * Mx[j * N + r];
+      Mx[k * N + r] = a / x;
+    }
+  }
+  return fail;
+}
+
 // LLT::solve(Identity) following Eigen's small triangular solver (reciprocal then multiply)
 template <int N>
 MAS_HD void llt_solve_identity(const double* Lm, double* Inv) {
