@@ -49,6 +49,8 @@ MAS_HD void st_off(double* base, unsigned byte_off, double v) { *reinterpret_cas
 //    each chunk as ONE contiguous, 64-byte-aligned run of 64*cw_c doubles (8 KiB): full-line stores only;
 //  * the backward pass (a wavefront = 4 consecutive agents) reads 4*cw_c contiguous doubles per chunk.
 constexpr int kTileChunk = 16;
+// lanes that share one agent's backward recursion (mas_backward_tile_kernel): 16 or 32; 64 / this = agents per wavefront
+constexpr int kBackwardLanesPerAgent = 16;   // measured on C3: 16 -> 145 us per launch, 32 -> 165 us
 MAS_HD size_t tile_offset(int nd, size_t Np, int t, int a, int e) {
   const int c = e / kTileChunk, cw = (nd - c * kTileChunk < kTileChunk) ? (nd - c * kTileChunk) : kTileChunk;
   return (static_cast<size_t>(t) * (Np / 64) + static_cast<size_t>(a / 64)) * 64 * nd + static_cast<size_t>(c) * kTileChunk * 64 +

@@ -106,17 +106,19 @@ struct BackwardTileLayout {
 //            registers: each lane rebuilds the two gain columns and the two rows of K^T q_uu it needs,
 //            evaluates its own and its mirror entry of v_xx and applies the reference's aliased
 //            in-place symmetrisation rule, so no further exchange is needed.
-template <class M>
+template <class M, int LPA>
 __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
                                                                double* __restrict__ kff, double* __restrict__ Kfb,
                                                                long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n) {
   using TL = BackwardTileLayout<M>;
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
-  constexpr int APW = 4, LPA = 16;                  // agents per wavefront, lanes per agent
+  constexpr int APW = 64 / LPA;                     // agents per wavefront (LPA lanes per agent)
+  constexpr int LL = 16;                            // ladder width: rungs tried at once (lanes beyond LL repeat rung lane % LL)
+  static_assert(LPA >= LL && 64 % LPA == 0, "lanes per agent");
   __shared__ double lds[APW * TL::STRIDE];
 
-  const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid >> 4;
+  const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
   const int a0 = lo + blockIdx.x * APW, a = a0 + slot;
   const bool valid = (a < n) && active[a] != 0;
   if (__ballot(valid) == 0ull) return;              // uniform for the (single-wave) block
@@ -180,10 +182,10 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   long long regs = 0;
   // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
   // reference's `reg *= 10.0`) for the q < lane rungs it has to apply, -0.0 (adds nothing, changes no bit) after
-  double rung_add[LPA - 1];
+  double rung_add[LL - 1];
   {
     double reg = 1e-6;
-    MAS_UNROLL for (int q = 0; q < LPA - 1; ++q) { rung_add[q] = (q < lane) ? reg : -0.0; reg *= 10.0; }
+    MAS_UNROLL for (int q = 0; q < LL - 1; ++q) { rung_add[q] = (q < rung_lane) ? reg : -0.0; reg *= 10.0; }
   }
   // gain stores: uniform per-step base pointers + loop-invariant 32-bit byte offsets (row * Np + agent) * 8
   constexpr int RMX = (NX * NX + LPA - 1) / LPA;
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = quu[i];
         // the additions stay sequential (floating-point addition is not associative): straight-line code
         // over the lane's precomputed addends, lane r applying the first r of them
-        MAS_UNROLL for (int q = 0; q < LPA - 1; ++q) {
+        MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
           MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += rung_add[q];
         }
         // rungs 0..15 first, as straight-line code (three out of four steps need no regularisation at all and
@@ -260,12 +262,12 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
           double reg_next = 0.0;                                       // this lane's next rung value
           int base = 0;
           for (;;) {
-            if (win < 0 && base + LPA > kRegLadderMax) win = base + LPA - 1;   // guard, never reached (see kRegLadderMax)
+            if (win < 0 && base + LL > kRegLadderMax) win = base + LL - 1;     // guard, never reached (see kRegLadderMax)
             if (__ballot(win < 0) == 0ull) break;                              // every agent of the wavefront is settled
             if (win < 0) {
-              if (base == 0) { reg_next = 1e-6; for (int q = 0; q < lane; ++q) reg_next *= 10.0; }
-              for (int q = 0; q < LPA; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
-              base += LPA;
+              if (base == 0) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+              for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
+              base += LL;
             }
             double Ltry[NU * NU];
             MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Ltry[i] = cur[i];
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
             }
           }
         }
-        if (lane == (win & (LPA - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oAtV + i] = Lfac[i]; }   // oAtV is dead after pass 2
+        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oAtV + i] = Lfac[i]; }   // oAtV is dead after pass 2
         if (lane == 0) regs += win;
         __syncthreads();
         MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oAtV + i];

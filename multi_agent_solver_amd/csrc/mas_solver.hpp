@@ -391,7 +391,8 @@ class SolverImpl final : public SolverBase {
       return;
     }
     be.begin("backward", bytes);
-    be.launch_kernel(mas_backward_tile_kernel<M>, dim3((hi - lo + 3) / 4), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
+    constexpr int apw = 64 / kBackwardLanesPerAgent;
+    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent>, dim3((hi - lo + apw - 1) / apw), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
     be.end();
 #endif
   }
