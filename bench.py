@@ -35,11 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def shard_range(n_total: int, world: int, rank: int):
-    """contiguous ranges of the id-sorted block list (multi_agent_problem.hpp:41-49), one per rank"""
-    base, rem = divmod(n_total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+from multi_agent_solver_amd.dist import shard_range  # noqa: E402  contiguous ranges of the id-sorted block list, one per rank
 
 
 WORKLOADS = {

@@ -122,6 +122,17 @@ int mas_hip_run_line_search(mas_hip_solver*, int max_outer);
  * reading of the stacked problem: shared alpha / acceptance / termination / regularisation */
 int mas_hip_run_centralized(mas_hip_solver*);
 
+/* ---- agents sharded over ranks (one handle per GPU): the one exchange the Nash strategies have ----
+ * detail::compute_total_cost (nash.hpp:45-49) sums the cost of ALL agents; run_line_search accepts or rejects a
+ * joint step on that sum (nash.hpp:119,134-143).  When the id-sorted block list is sharded over ranks, the caller
+ * installs this callback: it receives this handle's per-agent costs (host pointer, n_local doubles, block order)
+ * and must return in *global_total the sum over every rank's agents accumulated serially in global block order
+ * (rank 0's agents first) -- the value a single handle holding all agents computes, so that every rank takes the
+ * same decisions.  Non-zero return aborts the strategy call with MAS_HIP_ERR_RUNTIME.  NULL (default): local sum.
+ * The sequential and trust-region strategies exchange nothing (nash.hpp:59-64,200-212: agents are decoupled). */
+typedef int (*mas_hip_cost_exchange_fn)(void* ctx, const double* local_costs, int32_t n_local, double* global_total);
+int mas_hip_set_cost_exchange(mas_hip_solver*, mas_hip_cost_exchange_fn fn, void* ctx);
+
 /* ---- results: OCP::best_states/best_controls/best_cost; Solution (solution.hpp:9-15) ---- */
 int mas_hip_get_solution_host(mas_hip_solver*, double* X /* [N][T+1][nx] */, double* U /* [N][T][nu] */,
                               double* cost /* [N] */, int32_t* iterations /* [N] */, int32_t* exit_status /* [N] */);

@@ -27,7 +27,7 @@ EXPORTS = [
     "mas_hip_solve", "mas_hip_run_sequential", "mas_hip_run_trust_region", "mas_hip_run_line_search",
     "mas_hip_run_centralized",
     "mas_hip_get_solution_host", "mas_hip_get_solution_device", "mas_hip_total_cost",
-    "mas_hip_get_trust_radii_host", "mas_hip_debug_backward_host",
+    "mas_hip_set_cost_exchange", "mas_hip_get_trust_radii_host", "mas_hip_debug_backward_host",
     "mas_hip_get_stats", "mas_hip_reset_stats", "mas_hip_set_profiling", "mas_hip_get_kernel_times",
 ]
 
@@ -37,6 +37,10 @@ class ProblemDesc(C.Structure):
                 ("device", C.c_int32), ("dt", C.c_double), ("params", C.POINTER(C.c_double)),
                 ("input_lower_bounds", C.POINTER(C.c_double)), ("input_upper_bounds", C.POINTER(C.c_double)),
                 ("no_input_bounds", C.c_int32), ("reserved", C.c_int32)]
+
+
+# int (*mas_hip_cost_exchange_fn)(void* ctx, const double* local_costs, int32_t n_local, double* global_total)
+COST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double))
 
 
 class Stats(C.Structure):
@@ -101,6 +105,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     lib.mas_hip_get_solution_host.argtypes = [vp, d, d, d, i32, i32]
     lib.mas_hip_get_solution_device.argtypes = [vp, vp, vp, vp]
     lib.mas_hip_total_cost.argtypes = [vp, d]
+    lib.mas_hip_set_cost_exchange.argtypes = [vp, COST_EXCHANGE_FN, C.c_void_p]
     lib.mas_hip_get_trust_radii_host.argtypes = [vp, d]
     lib.mas_hip_debug_backward_host.argtypes = [vp, d, d, d, C.POINTER(C.c_int64)]
     lib.mas_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]

@@ -119,6 +119,25 @@ class BatchSolver:
     def restore_initial(self):
         self._check(self._lib.mas_hip_restore_initial(self._h))
 
+    # -- agents sharded over ranks ---------------------------------------------------------
+    def set_cost_exchange(self, fn):
+        """fn(local_costs: np.ndarray[n_local]) -> float: total cost over ALL ranks' agents, summed serially in global
+        block order (mas_hip_set_cost_exchange; nash.hpp:45-49).  None restores the local sum."""
+        if fn is None:
+            self._exchange_cb = None
+            self._check(self._lib.mas_hip_set_cost_exchange(self._h, _capi.COST_EXCHANGE_FN(0), None))
+            return
+
+        def _cb(_ctx, costs, n, out):
+            try:
+                out[0] = float(fn(np.ctypeslib.as_array(costs, shape=(n,)).copy()))
+                return 0
+            except Exception:   # never let an exception cross the C boundary
+                return 1
+
+        self._exchange_cb = _capi.COST_EXCHANGE_FN(_cb)   # keep the trampoline alive as long as the handle uses it
+        self._check(self._lib.mas_hip_set_cost_exchange(self._h, self._exchange_cb, None))
+
     # -- hot path ------------------------------------------------------------------------
     def solve(self):
         self._check(self._lib.mas_hip_solve(self._h))

@@ -126,6 +126,9 @@ int mas_hip_total_cost(mas_hip_solver* h, double* total) {
   if (!total) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) { *total = s.total_cost(); });
 }
+int mas_hip_set_cost_exchange(mas_hip_solver* h, mas_hip_cost_exchange_fn fn, void* ctx) {
+  return guarded(h, [&](mas::SolverBase& s) { s.cost_exchange = fn; s.cost_exchange_ctx = ctx; });
+}
 int mas_hip_get_trust_radii_host(mas_hip_solver* h, double* radii) {
   if (!radii) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) { s.get_trust_radii(radii); });

@@ -74,6 +74,11 @@ class SolverBase {
   }
   bool params_complete() const { return has_max_iterations && has_tolerance && has_max_ms; }
 
+  // total cost over all ranks' agents when the block list is sharded (mas_hip_set_cost_exchange); null = local
+  using CostExchange = int (*)(void* ctx, const double* local_costs, int32_t n_local, double* global_total);
+  CostExchange cost_exchange = nullptr;
+  void* cost_exchange_ctx = nullptr;
+
   Backend be;
   std::string last_error;
   // defaults of the iLQR constructor, ilqr.hpp:26-37
@@ -204,18 +209,18 @@ class SolverImpl final : public SolverBase {
     Timer tm(*this);
     ensure_initialized();
     ensure_snapshots();
-    double base_cost = host_sum(cost);
+    double base_cost = joint_sum(cost);
     for (int outer = 0; outer < max_outer; ++outer) {
       be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
       be.d2d(cost_old, cost, sizeof(double) * d.Np);
       solve_all();
-      const double new_cost = host_sum(cost);
+      const double new_cost = joint_sum(cost);
       if (new_cost >= base_cost) {
         be.d2d(U_cand, U, sizeof(double) * d.T * NU * d.Np);
         double alpha = 0.5; bool accepted = false;
         while (alpha > 1e-3 && !accepted) {
           be.template launch_1d<1>("blend_rollout", BlendRolloutBody<M>{d, dt, alpha, P, x0, U_old, U_cand, X, U, cost}, d.N);
-          const double trial_cost = host_sum(cost);
+          const double trial_cost = joint_sum(cost);
           if (trial_cost < base_cost) { base_cost = trial_cost; accepted = true; }
           else alpha *= 0.5;
         }
@@ -510,6 +515,15 @@ class SolverImpl final : public SolverBase {
     last_solve_rounds = rounds_this_solve;
   }
 
+  // detail::compute_total_cost over ALL agents (nash.hpp:45-49): through the caller's exchange when the block
+  // list is sharded over ranks, the local serial sum otherwise
+  double joint_sum(const double* dev) {
+    if (!cost_exchange) return host_sum(dev);
+    std::vector<double> h(d.N); be.d2h(h.data(), dev, sizeof(double) * d.N);
+    double total = 0.0;
+    if (cost_exchange(cost_exchange_ctx, h.data(), static_cast<int32_t>(d.N), &total) != 0) throw std::runtime_error("cost exchange callback failed");
+    return total;
+  }
   double host_sum(const double* dev) {      // Solution.total_cost: serial sum in block order (nash.hpp:23-37)
     std::vector<double> h(d.N); be.d2h(h.data(), dev, sizeof(double) * d.N);
     double c = 0.0; for (double v : h) c += v; return c;

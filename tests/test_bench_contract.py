@@ -45,3 +45,34 @@ def test_rccl_path_initialises_with_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     _check_line(j, 1)
+
+
+_RCCL_LINESEARCH = r"""
+import math, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
+from multi_agent_solver_amd.dist import make_cost_exchange
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+N, T = 64, 40
+def run(exchange):
+    with BatchSolver(1, N, T, 0.5) as s:
+        s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+        s.set_initial_states(single_track_x0(N)); s.set_controls(None)
+        if exchange: s.set_cost_exchange(make_cost_exchange(N))
+        s.run_line_search(3)
+        return s.solution()
+a, b = run(False), run(True)
+assert np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["X"], b["X"]) and np.array_equal(a["iters"], b["iters"])
+dist.destroy_process_group()
+print("RCCL_LINESEARCH_OK")
+"""
+
+
+def test_line_search_cost_exchange_over_rccl_matches_the_local_sum():
+    """the one collective of the path (total cost of the line-search strategy, nash.hpp:45-49) through RCCL, one rank"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29546")
+    out = subprocess.run([sys.executable, "-c", _RCCL_LINESEARCH % {"root": ROOT}], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0 and "RCCL_LINESEARCH_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])

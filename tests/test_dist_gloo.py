@@ -69,6 +69,55 @@ def test_two_rank_sharding_matches_single_process(hostcheck_lib, tmp_path):
     assert got["tmax"] == 2.0
 
 
+def _linesearch_worker(rank, world, port, n_total, T, max_outer, hostcheck_path, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from multi_agent_solver_amd import _capi
+    from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
+    from multi_agent_solver_amd.dist import make_cost_exchange, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _capi.load(hostcheck_path)
+    lo, hi = shard_range(n_total, world, rank)
+    calls = []
+    exchange = make_cost_exchange(n_total)
+
+    def counted(costs):
+        calls.append(len(costs))
+        return exchange(costs)
+
+    with BatchSolver(1, hi - lo, T, 0.5, lib=lib) as s:
+        s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+        s.set_initial_states(single_track_x0(hi - lo, first=lo, total=n_total))
+        s.set_controls(None)
+        s.set_cost_exchange(counted)
+        s.run_line_search(max_outer)
+        sol = s.solution()
+    np.savez(out % rank, cost=sol["cost"], X=sol["X"], U=sol["U"], iters=sol["iters"], calls=len(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_line_search_takes_the_single_process_decisions(hostcheck_lib, tmp_path):
+    """The line-search strategy accepts / rejects a joint step on the total cost of ALL agents (nash.hpp:119,134-143):
+    sharded over two ranks with the all-gather exchange it must reproduce the one-handle run bit for bit."""
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    from conftest import run_batch
+    from multi_agent_solver_amd.batch import single_track_x0
+    n_total, T, max_outer = 7, 20, 3       # 4 + 3 agents: uneven shards exercise the padding of the all-gather
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_linesearch_worker, args=(2, _free_port(), n_total, T, max_outer, g.HOSTCHECK, out), nprocs=2, join=True)
+    parts = [np.load(out % r) for r in range(2)]
+    ref = run_batch(hostcheck_lib, 1, single_track_x0(n_total), None, T, 0.5, "linesearch", max_outer=max_outer)
+    assert np.array_equal(np.concatenate([p["cost"] for p in parts]), ref["cost"])
+    assert np.array_equal(np.concatenate([p["X"] for p in parts]), ref["X"])
+    assert np.array_equal(np.concatenate([p["U"] for p in parts]), ref["U"])
+    assert np.array_equal(np.concatenate([p["iters"] for p in parts]), ref["iters"])
+    assert parts[0]["calls"] == parts[1]["calls"] >= 1 + max_outer   # same number of exchanges on both ranks (no deadlock by construction)
+
+
 def test_shard_ranges_cover_the_block_list():
     sys.path.insert(0, ROOT)
     from bench import shard_range
