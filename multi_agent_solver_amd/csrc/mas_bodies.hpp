@@ -264,9 +264,11 @@ struct SelectBody {
   long long* clear;           // counter pair of the ring that the round after next will use: reset here
   const double* trial_obj = nullptr;   // objective of the trials when it differs from the merit (constraint functions)
   double* improvement_out = nullptr;   // non-null: termination is decided by ALUpdateBody after the multiplier update
-  MAS_HD void operator()(int a) const {
+  // what became of agent a in this iteration
+  enum Outcome { kIdle = 0, kStillActive = 1, kConverged = 2, kRetired = 3 };
+  MAS_HD int decide(int a) const {
     if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
-    if (!active[a]) { alpha_sel[a] = -1; return; }
+    if (!active[a]) { alpha_sel[a] = -1; return kIdle; }
     const double cur = merit[a];
     int sel = -1; double best = cur;
     for (int j = 0; j < kNumAlphas; ++j) {
@@ -278,15 +280,21 @@ struct SelectBody {
     if (sel >= 0) { cost[a] = trial_obj ? trial_obj[static_cast<size_t>(sel) * d.Np + a] : best; merit[a] = best; }   // cost = objective(best_x,best_u); current_merit = best_merit
     const int it = iters_solve[a] + 1;
     iters_solve[a] = it; iters_total[a] += 1;
-    if (improvement_out) { improvement_out[a] = improvement; return; }
+    if (improvement_out) { improvement_out[a] = improvement; return kIdle; }
     if (improvement < tolerance) {                          // ilqr.hpp:269-271
       active[a] = 0; exit_code[a] = kExitConverged | (std::isfinite(best) ? 0 : kExitNonFinite);
-      MAS_ATOMIC_ADD_I64(n_converged, 1LL);
-    } else if (it >= max_iterations) {                      // ilqr.hpp:82
-      active[a] = 0; exit_code[a] = kExitMaxIter | (std::isfinite(best) ? 0 : kExitNonFinite);
-    } else {
-      MAS_ATOMIC_ADD_INT(n_active, 1);
+      return kConverged;
     }
+    if (it >= max_iterations) {                             // ilqr.hpp:82
+      active[a] = 0; exit_code[a] = kExitMaxIter | (std::isfinite(best) ? 0 : kExitNonFinite);
+      return kRetired;
+    }
+    return kStillActive;
+  }
+  MAS_HD void operator()(int a) const {
+    const int r = decide(a);
+    if (r == kConverged) MAS_ATOMIC_ADD_I64(n_converged, 1LL);
+    else if (r == kStillActive) MAS_ATOMIC_ADD_INT(n_active, 1);
   }
 };
 
@@ -347,7 +355,13 @@ struct ALUpdateBody {
 // zeroes the gains, ilqr.hpp:292-293; they are rewritten before use so nothing to clear here)
 struct BeginSolveBody {
   int* active; int* iters_solve; int* exit_code; int* alpha_sel;
-  MAS_HD void operator()(int a) const { active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1; }
+  const double* cost = nullptr; double* merit = nullptr;      // non-null: current_merit = objective (ilqr.hpp:78) when the rollout is already on the device
+  long long* counters = nullptr; int n_counters = 0;           // the round counters of the solve, zeroed by agent 0
+  MAS_HD void operator()(int a) const {
+    active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1;
+    if (merit) merit[a] = cost[a];
+    if (a == 0) { for (int i = 0; i < n_counters; ++i) counters[i] = 0; }
+  }
 };
 
 struct MarkTimeoutBody {

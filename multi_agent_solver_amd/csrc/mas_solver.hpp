@@ -121,9 +121,9 @@ class SolverImpl final : public SolverBase {
     cost = dalloc(Np); merit = dalloc(Np);
     x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
     active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
-    reg_events = static_cast<long long*>(be.alloc(sizeof(long long) * Np));
-    counters = static_cast<long long*>(be.alloc(sizeof(long long) * 32));
-    central = static_cast<CentralState*>(be.alloc(sizeof(CentralState)));
+    reg_events = static_cast<long long*>(raw_alloc(sizeof(long long) * Np));
+    counters = static_cast<long long*>(raw_alloc(sizeof(long long) * 32));
+    central = static_cast<CentralState*>(raw_alloc(sizeof(CentralState)));
     if constexpr (kConstrained) {
       if (M::NEQ > 0) al_lam = dalloc(static_cast<size_t>(T) * M::NEQ * Np);
       if (M::NIN > 0) al_mu = dalloc(static_cast<size_t>(T) * M::NIN * Np);
@@ -373,7 +373,7 @@ class SolverImpl final : public SolverBase {
     const dim3 grid((hi - lo + 63) / 64, (d.T + 3) / 4);
     if (be.profiling) {                                   // in-kernel REFCLK stamps for the roofline kernel
       const size_t per_launch = 2 * static_cast<size_t>(grid.x) * grid.y;
-      if (!sweep_stamps) { stamp_capacity = per_launch * kMaxStampedLaunches; sweep_stamps = static_cast<unsigned long long*>(be.alloc(sizeof(unsigned long long) * stamp_capacity)); }
+      if (!sweep_stamps) { stamp_capacity = per_launch * kMaxStampedLaunches; sweep_stamps = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * stamp_capacity)); }
       if (stamp_used + per_launch <= stamp_capacity) {
         stamp = sweep_stamps + stamp_used;
         MAS_HIP_CHECK(hipMemsetAsync(stamp, 0, sizeof(unsigned long long) * per_launch, be.cur));
@@ -437,19 +437,19 @@ class SolverImpl final : public SolverBase {
   // round is bound by each agent's own sequential chain -- DESIGN.md section 4.)
   void solve_all() {
     ensure_initialized();
-    be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
     // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78).  After
     // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
     // rollout and cost (same kernels, same arithmetic, bit for bit), so it is only redone when the
     // controls were replaced from outside.
     if (kConstrained && al_enabled) { sync_penalty(); rollout_consistent = false; }   // merit depends on the current multipliers
+    // begin_solve also sets current_merit = compute_merit(x,u) == objective (ilqr.hpp:78) when no rollout follows,
+    // and zeroes the round counters
+    be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
+                                                           counters, 2 * kCounterRing}, d.N);
     if (!rollout_consistent) {
       be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
       rollout_consistent = true;
-    } else {
-      be.d2d(merit, cost, sizeof(double) * d.Np);   // current_merit = compute_merit(x,u) == objective (ilqr.hpp:78)
     }
-    be.zero(counters, sizeof(long long) * 2 * kCounterRing);
     stats.solves += d.N;
     if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
     const auto t0 = std::chrono::steady_clock::now();
@@ -473,9 +473,10 @@ class SolverImpl final : public SolverBase {
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
       const bool al_round = kConstrained && al_enabled;
-      be.template launch_1d<1>("select", SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
-                                                    iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
-                                                    al_round ? trial_obj : nullptr, al_round ? improvement : nullptr}, d.N);
+      const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
+                           iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
+                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr};
+      be.template launch_1d<1>("select", sel, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       if constexpr (kConstrained) {
         if (al_round)
@@ -532,6 +533,7 @@ class SolverImpl final : public SolverBase {
   void fill_int(int* dev, int v) { std::vector<int> h(d.Np, v); be.h2d(dev, h.data(), sizeof(int) * d.Np); }
   void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); } else be.h2d(stage, src, sizeof(double) * n); }
   void download(double* dst, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(dst, stage, sizeof(double) * n); be.sync(); } else be.d2h(dst, stage, sizeof(double) * n); }
+  void* raw_alloc(size_t bytes) { void* p = be.alloc(bytes); allocations.push_back(p); return p; }   // freed by the destructor
   double* dalloc(size_t n) { void* p = be.alloc(sizeof(double) * n); allocations.push_back(p); return static_cast<double*>(p); }
   int* ialloc(size_t n) { void* p = be.alloc(sizeof(int) * n); allocations.push_back(p); return static_cast<int*>(p); }
 
