@@ -264,6 +264,7 @@ struct SelectBody {
   long long* clear;           // counter pair of the ring that the round after next will use: reset here
   const double* trial_obj = nullptr;   // objective of the trials when it differs from the merit (constraint functions)
   double* improvement_out = nullptr;   // non-null: termination is decided by ALUpdateBody after the multiplier update
+  int* next_list = nullptr;            // non-null: the agents still active, compacted (slot = value of n_active when it was counted)
   // what became of agent a in this iteration
   enum Outcome { kIdle = 0, kStillActive = 1, kConverged = 2, kRetired = 3 };
   MAS_HD int decide(int a) const {
@@ -293,8 +294,23 @@ struct SelectBody {
   }
   MAS_HD void operator()(int a) const {
     const int r = decide(a);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one atomic per wavefront and counter; the returned base gives every still-active agent its slot in the
+    // compacted list that the next iteration's sweep walks
+    const unsigned long long still = __ballot(r == kStillActive), conv = __ballot(r == kConverged);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    if (conv != 0ull && lane == __builtin_ctzll(conv)) MAS_ATOMIC_ADD_I64(n_converged, static_cast<long long>(__popcll(conv)));
+    if (still != 0ull) {
+      const int leader = __builtin_ctzll(still);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(n_active, __popcll(still));
+      base = __shfl(base, leader);
+      if (next_list && r == kStillActive) next_list[base + __popcll(still & ((1ull << lane) - 1ull))] = a;
+    }
+#else
     if (r == kConverged) MAS_ATOMIC_ADD_I64(n_converged, 1LL);
-    else if (r == kStillActive) MAS_ATOMIC_ADD_INT(n_active, 1);
+    else if (r == kStillActive) { if (next_list) next_list[*n_active] = a; MAS_ATOMIC_ADD_INT(n_active, 1); }
+#endif
   }
 };
 
@@ -357,10 +373,12 @@ struct BeginSolveBody {
   int* active; int* iters_solve; int* exit_code; int* alpha_sel;
   const double* cost = nullptr; double* merit = nullptr;      // non-null: current_merit = objective (ilqr.hpp:78) when the rollout is already on the device
   long long* counters = nullptr; int n_counters = 0;           // the round counters of the solve, zeroed by agent 0
+  int* live_list = nullptr; int* live_count = nullptr; int n_agents = 0;   // every agent is active: identity list
   MAS_HD void operator()(int a) const {
     active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1;
     if (merit) merit[a] = cost[a];
-    if (a == 0) { for (int i = 0; i < n_counters; ++i) counters[i] = 0; }
+    if (live_list) live_list[a] = a;
+    if (a == 0) { for (int i = 0; i < n_counters; ++i) counters[i] = 0; if (live_count) *live_count = n_agents; }
   }
 };
 

@@ -120,6 +120,7 @@ class SolverImpl final : public SolverBase {
     trial_merit = dalloc(static_cast<size_t>(kNumAlphas) * Np);
     cost = dalloc(Np); merit = dalloc(Np);
     x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
+    live_list = ialloc(Np); live_count0 = ialloc(16);
     active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
     reg_events = static_cast<long long*>(raw_alloc(sizeof(long long) * Np));
     counters = static_cast<long long*>(raw_alloc(sizeof(long long) * 32));
@@ -359,8 +360,10 @@ class SolverImpl final : public SolverBase {
 
   // linearisation sweep: on the GPU a dedicated kernel that stages each wavefront's tiles through
   // LDS (mas_kernels_hip.hpp); the host emulation replays the plain body
+  // live_count != nullptr: walk the compacted list of active agents (live_list) instead of the active flags
   void launch_sweep(double bytes) { launch_sweep(bytes, 0, d.N); }
-  void launch_sweep(double bytes, int lo, int hi) {
+  void launch_sweep(double bytes, int lo, int hi, const int* live_count = nullptr) {
+    (void)live_count;
 #if defined(MAS_HOST_EMULATION)
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
 #else
@@ -381,7 +384,8 @@ class SolverImpl final : public SolverBase {
         stamp_used += per_launch;
       }
     }
-    be.launch_kernel(mas_sweep_kernel<M>, grid, dim3(64, 4), d, P, X, U, D, active, lo, hi, stamp);
+    be.launch_kernel(mas_sweep_kernel<M>, grid, dim3(64, 4), d, P, X, U, D, active, lo, hi, stamp,
+                     static_cast<const int*>(live_count ? live_list : nullptr), live_count);
     be.end();
 #endif
   }
@@ -445,7 +449,7 @@ class SolverImpl final : public SolverBase {
     // begin_solve also sets current_merit = compute_merit(x,u) == objective (ilqr.hpp:78) when no rollout follows,
     // and zeroes the round counters
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
-                                                           counters, 2 * kCounterRing}, d.N);
+                                                           counters, 2 * kCounterRing, live_list, live_count0, d.N}, d.N);
     if (!rollout_consistent) {
       be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
       rollout_consistent = true;
@@ -467,15 +471,18 @@ class SolverImpl final : public SolverBase {
       Marks& mk = marks[r & 1];
       mk.p0 = be.mark(); mk.s0 = stamp_launches.size();
       // byte counts are per agent here and scaled by the round's active-agent count once it is known
-      launch_sweep(sweep_bytes(), 0, d.N);
+      // the sweep walks the agents the previous round's select left active (all of them in round 0); with the
+      // augmented-Lagrangian update deciding termination after select, the list is not built and the flags are used
+      const bool al_round = kConstrained && al_enabled;
+      const int* live = al_round ? nullptr : (r == 0 ? live_count0 : reinterpret_cast<const int*>(counters + 2 * ((r - 1) % kCounterRing)));
+      launch_sweep(sweep_bytes(), 0, d.N, live);
       launch_backward(backward_bytes(), 0, d.N);
       be.template launch_2d_range<1>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
-      const bool al_round = kConstrained && al_enabled;
       const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
-                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr};
+                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : live_list};
       be.template launch_1d<1>("select", sel, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       if constexpr (kConstrained) {
@@ -544,6 +551,7 @@ class SolverImpl final : public SolverBase {
   double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
+  int *live_list = nullptr, *live_count0 = nullptr;   // agents still active, compacted by select; count of round 0 (= N)
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
   CentralState *central = nullptr, *host_central = nullptr;
