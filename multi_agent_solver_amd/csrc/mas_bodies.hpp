@@ -265,8 +265,18 @@ struct SelectBody {
   const double* trial_obj = nullptr;   // objective of the trials when it differs from the merit (constraint functions)
   double* improvement_out = nullptr;   // non-null: termination is decided by ALUpdateBody after the multiplier update
   int* next_list = nullptr;            // non-null: the agents still active, compacted (slot = value of n_active when it was counted)
-  // what became of agent a in this iteration
-  enum Outcome { kIdle = 0, kStillActive = 1, kConverged = 2, kRetired = 3 };
+  int* solves_left = nullptr;          // non-null: an agent whose solve ends starts its next one at once (chained solves, see begin_chain)
+  // what became of agent a in this iteration; bit 2 = its solve ended but it goes straight on with its next solve
+  enum Outcome { kIdle = 0, kStillActive = 1, kConverged = 2, kRetired = 3, kChained = 4 };
+  // detail::run_sequential (nash.hpp:74-90) calls solve() on every agent max_outer times, and an agent's solve k+1
+  // depends on nothing but its own solve k: the new solver state is iteration count 0, and trajectory, cost and
+  // merit are what solve k left (its rollout of best_controls, bit for bit).  So the agent does not wait for the
+  // others at a host-side barrier; it simply stays active.
+  MAS_HD bool begin_chain(int a) const {
+    if (!solves_left || solves_left[a] <= 0) return false;
+    solves_left[a] -= 1; iters_solve[a] = 0;
+    return true;
+  }
   MAS_HD int decide(int a) const {
     if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
     if (!active[a]) { alpha_sel[a] = -1; return kIdle; }
@@ -283,11 +293,15 @@ struct SelectBody {
     iters_solve[a] = it; iters_total[a] += 1;
     if (improvement_out) { improvement_out[a] = improvement; return kIdle; }
     if (improvement < tolerance) {                          // ilqr.hpp:269-271
-      active[a] = 0; exit_code[a] = kExitConverged | (std::isfinite(best) ? 0 : kExitNonFinite);
+      exit_code[a] = kExitConverged | (std::isfinite(best) ? 0 : kExitNonFinite);
+      if (begin_chain(a)) return kConverged | kChained;
+      active[a] = 0;
       return kConverged;
     }
     if (it >= max_iterations) {                             // ilqr.hpp:82
-      active[a] = 0; exit_code[a] = kExitMaxIter | (std::isfinite(best) ? 0 : kExitNonFinite);
+      exit_code[a] = kExitMaxIter | (std::isfinite(best) ? 0 : kExitNonFinite);
+      if (begin_chain(a)) return kRetired | kChained;
+      active[a] = 0;
       return kRetired;
     }
     return kStillActive;
@@ -297,7 +311,8 @@ struct SelectBody {
 #if defined(__HIP_DEVICE_COMPILE__)
     // one atomic per wavefront and counter; the returned base gives every still-active agent its slot in the
     // compacted list that the next iteration's sweep walks
-    const unsigned long long still = __ballot(r == kStillActive), conv = __ballot(r == kConverged);
+    const bool goes_on = r == kStillActive || (r & kChained) != 0;
+    const unsigned long long still = __ballot(goes_on), conv = __ballot((r & ~kChained) == kConverged);
     const int lane = static_cast<int>(threadIdx.x) & 63;
     if (conv != 0ull && lane == __builtin_ctzll(conv)) MAS_ATOMIC_ADD_I64(n_converged, static_cast<long long>(__popcll(conv)));
     if (still != 0ull) {
@@ -305,11 +320,11 @@ struct SelectBody {
       int base = 0;
       if (lane == leader) base = atomicAdd(n_active, __popcll(still));
       base = __shfl(base, leader);
-      if (next_list && r == kStillActive) next_list[base + __popcll(still & ((1ull << lane) - 1ull))] = a;
+      if (next_list && goes_on) next_list[base + __popcll(still & ((1ull << lane) - 1ull))] = a;
     }
 #else
-    if (r == kConverged) MAS_ATOMIC_ADD_I64(n_converged, 1LL);
-    else if (r == kStillActive) { if (next_list) next_list[*n_active] = a; MAS_ATOMIC_ADD_INT(n_active, 1); }
+    if ((r & ~kChained) == kConverged) MAS_ATOMIC_ADD_I64(n_converged, 1LL);
+    if (r == kStillActive || (r & kChained) != 0) { if (next_list) next_list[*n_active] = a; MAS_ATOMIC_ADD_INT(n_active, 1); }
 #endif
   }
 };
@@ -374,8 +389,10 @@ struct BeginSolveBody {
   const double* cost = nullptr; double* merit = nullptr;      // non-null: current_merit = objective (ilqr.hpp:78) when the rollout is already on the device
   long long* counters = nullptr; int n_counters = 0;           // the round counters of the solve, zeroed by agent 0
   int* live_list = nullptr; int* live_count = nullptr; int n_agents = 0;   // every agent is active: identity list
+  int* solves_left = nullptr; int chained = 0;                 // further solves every agent runs back to back after this one
   MAS_HD void operator()(int a) const {
     active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1;
+    if (solves_left) solves_left[a] = chained;
     if (merit) merit[a] = cost[a];
     if (live_list) live_list[a] = a;
     if (a == 0) { for (int i = 0; i < n_counters; ++i) counters[i] = 0; if (live_count) *live_count = n_agents; }

@@ -120,7 +120,7 @@ class SolverImpl final : public SolverBase {
     trial_merit = dalloc(static_cast<size_t>(kNumAlphas) * Np);
     cost = dalloc(Np); merit = dalloc(Np);
     x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
-    live_list = ialloc(Np); live_count0 = ialloc(16);
+    live_list = ialloc(Np); live_count0 = ialloc(16); solves_left = ialloc(Np);
     active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
     reg_events = static_cast<long long*>(raw_alloc(sizeof(long long) * Np));
     counters = static_cast<long long*>(raw_alloc(sizeof(long long) * 32));
@@ -186,7 +186,13 @@ class SolverImpl final : public SolverBase {
     reset_solver_state();   // the strategy creates fresh solver objects (nash.hpp:78-84)          // nash.hpp:74-90
     Timer tm(*this);
     ensure_initialized();
-    for (int outer = 0; outer < max_outer; ++outer) solve_all();   // update_initial_with_best (nash.hpp:66-71) has no device-side effect
+    // update_initial_with_best (nash.hpp:66-71) has no device-side effect, and an agent's solve k+1 depends only on
+    // its own solve k: the max_outer solves of every agent run back to back in one stream of rounds (no host
+    // barrier between outer iterations).  A wall-clock budget per solve (max_ms) or the multiplier update between
+    // solves needs the host between them, so those cases keep the loop.
+    const bool chain = max_outer > 1 && !(kConstrained && al_enabled) && !(max_ms < std::numeric_limits<double>::infinity());
+    if (chain) solve_all(max_outer);
+    else for (int outer = 0; outer < max_outer; ++outer) solve_all();
     last_total_valid = false;
   }
 
@@ -439,7 +445,8 @@ class SolverImpl final : public SolverBase {
   // agent, the already-enqueued round finds no active agent and every kernel exits at its first ballot --
   // results are unaffected.  (Agent ranges on separate streams were also tried: no gain at 4096 agents, the
   // round is bound by each agent's own sequential chain -- DESIGN.md section 4.)
-  void solve_all() {
+  // n_solves > 1: every agent performs that many consecutive solves (SelectBody::begin_chain)
+  void solve_all(int n_solves = 1) {
     ensure_initialized();
     // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78).  After
     // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
@@ -449,12 +456,14 @@ class SolverImpl final : public SolverBase {
     // begin_solve also sets current_merit = compute_merit(x,u) == objective (ilqr.hpp:78) when no rollout follows,
     // and zeroes the round counters
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
-                                                           counters, 2 * kCounterRing, live_list, live_count0, d.N}, d.N);
+                                                           counters, 2 * kCounterRing, live_list, live_count0, d.N,
+                                                           solves_left, n_solves - 1}, d.N);
     if (!rollout_consistent) {
       be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
       rollout_consistent = true;
     }
-    stats.solves += d.N;
+    stats.solves += static_cast<long long>(d.N) * n_solves;
+    const long long round_limit = static_cast<long long>(max_iterations) * n_solves;   // every solve ends after max_iterations rounds at the latest
     if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
     const auto t0 = std::chrono::steady_clock::now();
     const ForwardBody<M> fwd = make_forward();
@@ -463,7 +472,7 @@ class SolverImpl final : public SolverBase {
 #else
     // a solve that follows a one-round solve (the re-solves of outer rounds 2..max_outer usually are) would
     // waste its run-ahead round, so run ahead only while the previous solve needed several rounds
-    const bool run_ahead = last_solve_rounds != 1;
+    const bool run_ahead = n_solves > 1 || last_solve_rounds != 1;
 #endif
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
@@ -482,7 +491,8 @@ class SolverImpl final : public SolverBase {
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
       const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
-                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : live_list};
+                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : live_list,
+                           n_solves > 1 ? solves_left : nullptr};
       be.template launch_1d<1>("select", sel, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       if constexpr (kConstrained) {
@@ -500,7 +510,7 @@ class SolverImpl final : public SolverBase {
     if (max_iterations > 0 && !timed_out(t0)) { enqueue(0); enq = 1; }
     else if (max_iterations > 0) be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
     for (int r = 0; r < enq; ++r) {
-      if (run_ahead && enq == r + 1 && r + 1 < max_iterations && !timed_out(t0)) { enqueue(r + 1); ++enq; }
+      if (run_ahead && enq == r + 1 && r + 1 < round_limit && !timed_out(t0)) { enqueue(r + 1); ++enq; }
       be.wait(round_ev[r & 1]);
       const long long* hc = host_counters + 2 * (r % kCounterRing);
       const long long n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]);
@@ -514,7 +524,7 @@ class SolverImpl final : public SolverBase {
         if (enq > r + 1) { be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0); for (size_t q = marks[(r + 1) & 1].s0; q < marks[(r + 1) & 1].s1; ++q) stamp_launches[q].bytes = 0.0; }
         break;
       }
-      if (enq == r + 1 && r + 1 < max_iterations) {
+      if (enq == r + 1 && r + 1 < round_limit) {
         if (timed_out(t0)) { be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N); break; }
         enqueue(r + 1); ++enq;
       }
@@ -552,6 +562,7 @@ class SolverImpl final : public SolverBase {
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   int *live_list = nullptr, *live_count0 = nullptr;   // agents still active, compacted by select; count of round 0 (= N)
+  int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
   CentralState *central = nullptr, *host_central = nullptr;
