@@ -3,7 +3,8 @@
 //  * mas_sweep_kernel      linearisation sweep, one lane per (agent, t).  Each lane produces one
 //                          derivative tile (ND doubles) in registers; the wavefront stages the tiles
 //                          through LDS in 16-element chunks so that every global store instruction
-//                          writes contiguous 128-byte runs of the [t][agent][ND] tile array.
+//                          writes contiguous 128-byte runs of the [t][agent][ND] tile array.  Inside a solve
+//                          the wavefront slots walk the compacted list of still-active agents.
 //  * mas_backward_tile_kernel  backward Riccati recursion with SIXTEEN lanes per agent (a wavefront =
 //                          4 agents): the small dense products of ilqr.hpp:115-119,183-192 are spread
 //                          element-wise over the 16 lanes, operands live in an LDS tile per agent.
@@ -11,6 +12,10 @@
 //                          the one-lane-per-agent form (BackwardBody), which remains the host-emulated
 //                          statement of the same arithmetic: every output element is the same sequence
 //                          of multiplies and adds (sums in k order from 0.0), so results are bit-equal.
+//                          Its time-step loop is written against the gfx950 ISA it compiles to: a lone
+//                          wavefront per SIMD pays 5-7 clock ticks per instruction, so the loop avoids
+//                          selects (loop-invariant -0.0 addends), predication (clamped prefetch lanes)
+//                          and vector address arithmetic (scalar base + 32-bit lane offsets).
 //
 // No MFMA: v_mfma_f64_4x4x4 fuses the multiply-adds of a dot product, the reference (SSE2, no FMA;
 // CMakeLists.txt sets no -march) rounds after every multiply -- and the algorithm amplifies last-bit
