@@ -65,7 +65,7 @@ def one_step(s, w):
     s.run(w["strategy"], w["max_outer"])
 
 
-def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier):
+def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier, after=None):
     """Timed region: K steps with per-kernel instrumentation OFF (HIP events around every dispatch cost ~11 % of
     wall time on this latency-bound loop).  The kernel times / roofline come from a second pass of the same K
     steps, same process, same resident inputs, with the instrumentation ON."""
@@ -90,6 +90,8 @@ def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier):
     st["profiled_pass_elapsed"] = time.perf_counter() - t1
     kt = s.kernel_times()
     s.set_profiling(False)
+    if after is not None:
+        st["after"] = after(s)
     sol = s.solution()
     s.close()
     return elapsed, st, kt, sol
@@ -163,6 +165,9 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for a single rank (exercises the RCCL path on one GPU)")
+    ap.add_argument("--gather-solution", action="store_true",
+                    help="after the timed region, also time the all-gather of the whole Solution over RCCL (the publish step of coupled "
+                         "Nash problems, nash.hpp:66-71); reported as 'solution_all_gather', never part of 'value'")
     args = ap.parse_args()
 
     import torch
@@ -197,7 +202,18 @@ def main():
     n_total = per_gpu * world
     lo, hi = shard_range(n_total, world, rank)
 
-    elapsed, st, kt, _ = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier)
+    gather = None
+    if args.gather_solution and dist is not None:
+        def gather(solver):
+            from multi_agent_solver_amd.dist import all_gather_solution
+            times = []
+            for _ in range(3):
+                barrier(); sync(); t0 = time.perf_counter()
+                full = all_gather_solution(solver, n_total)
+                sync(); barrier(); times.append(time.perf_counter() - t0)
+            nbytes = sum(v.numel() * 8 for v in full.values())
+            return {"ms": 1e3 * min(times), "bytes_received_per_rank": nbytes, "GBs_per_rank": nbytes / min(times) / 1e9, "collective": "all_gather x3 (X, U, cost)"}
+    elapsed, st, kt, _ = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier, after=gather)
     vals = torch.tensor([elapsed, float(st["agent_iterations"]), float(st["converged_solves"]), float(st["solves"])],
                         dtype=torch.float64, device=("cuda" if args.backend == "nccl" else "cpu"))
     if dist is not None:
@@ -228,6 +244,8 @@ def main():
             "kernel_time_fraction_of_wall": total_kernel_ms * 1e-3 / st["profiled_pass_elapsed"],
             "instrumented_pass_ms_per_step": 1e3 * st["profiled_pass_elapsed"] / args.steps,
         }
+        if st.get("after") is not None:
+            out["solution_all_gather"] = st["after"]
         if world == 1 and not args.no_cpu_baseline:
             cb, _, _ = cpu_baseline(w, n_total)
             out["cpu_baseline"] = cb

@@ -43,3 +43,31 @@ def make_cost_exchange(n_total: int, group=None, device=None):
         return total
 
     return exchange
+
+
+def all_gather_solution(solver, n_total: int, group=None, device=None):
+    """Every rank receives the whole Solution (solution.hpp:9-15): states [n_total, T+1, nx], controls
+    [n_total, T, nu] and costs [n_total] in block order -- the publish step of the Nash strategies
+    (`update_initial_with_best`, nash.hpp:66-71) for callers whose agents are coupled through each other's
+    trajectories.  The shard leaves the solver through the device-pointer entry point (no host copy on a GPU) and
+    travels as ONE all-gather per array over RCCL/xGMI; shards are padded to equal size because an all-gather wants
+    equal shapes.  Returns torch tensors on `device`."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    spans = [shard_range(n_total, world, r) for r in range(world)]
+    width = max(hi - lo for lo, hi in spans)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    n_local = spans[rank][1] - spans[rank][0]
+    assert n_local == solver.N
+    X = torch.zeros((width, solver.T + 1, solver.nx), dtype=torch.float64, device=device)
+    U = torch.zeros((width, solver.T, solver.nu), dtype=torch.float64, device=device)
+    cost = torch.zeros(width, dtype=torch.float64, device=device)
+    solver.solution_device(X.data_ptr(), U.data_ptr(), cost.data_ptr())       # fills the first n_local agents
+    out = {}
+    for name, mine in (("X", X), ("U", U), ("cost", cost)):
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        out[name] = torch.cat([part[:hi - lo] for (lo, hi), part in zip(spans, parts)])
+    return out

@@ -40,11 +40,13 @@ def test_rccl_path_initialises_with_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29544", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
-                          "--agents-per-gpu", "256", "--force-dist", "--no-cpu-baseline", "--no-also"],
+                          "--agents-per-gpu", "256", "--force-dist", "--no-cpu-baseline", "--no-also", "--gather-solution"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     _check_line(j, 1)
+    g = j["solution_all_gather"]            # the optional publish all-gather went through RCCL on device tensors
+    assert g["ms"] > 0 and g["bytes_received_per_rank"] == 256 * (101 * 4 + 100 * 2 + 1) * 8
 
 
 _RCCL_LINESEARCH = r"""

@@ -74,7 +74,7 @@ def _linesearch_worker(rank, world, port, n_total, T, max_outer, hostcheck_path,
     sys.path.insert(0, ROOT)
     from multi_agent_solver_amd import _capi
     from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
-    from multi_agent_solver_amd.dist import make_cost_exchange, shard_range
+    from multi_agent_solver_amd.dist import all_gather_solution, make_cost_exchange, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -94,7 +94,9 @@ def _linesearch_worker(rank, world, port, n_total, T, max_outer, hostcheck_path,
         s.set_cost_exchange(counted)
         s.run_line_search(max_outer)
         sol = s.solution()
-    np.savez(out % rank, cost=sol["cost"], X=sol["X"], U=sol["U"], iters=sol["iters"], calls=len(calls))
+        full = all_gather_solution(s, n_total)          # the publish step: every rank holds the whole Solution
+    np.savez(out % rank, cost=sol["cost"], X=sol["X"], U=sol["U"], iters=sol["iters"], calls=len(calls),
+             full_X=full["X"].numpy(), full_U=full["U"].numpy(), full_cost=full["cost"].numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -116,6 +118,8 @@ def test_two_rank_line_search_takes_the_single_process_decisions(hostcheck_lib, 
     assert np.array_equal(np.concatenate([p["U"] for p in parts]), ref["U"])
     assert np.array_equal(np.concatenate([p["iters"] for p in parts]), ref["iters"])
     assert parts[0]["calls"] == parts[1]["calls"] >= 1 + max_outer   # same number of exchanges on both ranks (no deadlock by construction)
+    for p in parts:                                                   # all-gathered Solution == the one-handle Solution, on every rank
+        assert np.array_equal(p["full_X"], ref["X"]) and np.array_equal(p["full_U"], ref["U"]) and np.array_equal(p["full_cost"], ref["cost"])
 
 
 def test_shard_ranges_cover_the_block_list():
