@@ -90,7 +90,7 @@ const char* mas_hip_last_error(const mas_hip_solver*);   /* NULL handle: last cr
 
 /* ---- solver parameters: iLQR::set_params, ilqr.hpp:39-55 ----
  * keys "max_iterations", "tolerance", "max_ms" (required by the reference: params.at()),
- * optional "debug", "penalty", "penalty_increase", "constraint_tolerance",
+ * optional "debug" (one stdout line per batch round instead of one per agent and iteration), "penalty", "penalty_increase", "constraint_tolerance",
  * "inequality_activation_tolerance" (augmented-Lagrangian branch, ilqr.hpp:47-54);
  * unknown keys are ignored like the reference. */
 int mas_hip_set_param(mas_hip_solver*, const char* key, double value);

@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cmath>
+#include <iostream>
 #include <limits>
 #include <memory>
 
@@ -465,6 +466,7 @@ class SolverImpl final : public SolverBase {
     stats.solves += static_cast<long long>(d.N) * n_solves;
     const long long round_limit = static_cast<long long>(max_iterations) * n_solves;   // every solve ends after max_iterations rounds at the latest
     if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
+    if (debug) std::cout << "iLQR batch initial cost=" << host_sum(cost) << " agents=" << d.N << " solves_per_agent=" << n_solves << '\n';
     const auto t0 = std::chrono::steady_clock::now();
     const ForwardBody<M> fwd = make_forward();
 #if defined(MAS_HOST_EMULATION)
@@ -517,6 +519,8 @@ class SolverImpl final : public SolverBase {
       stats.agent_iterations += n_before;           // every agent active at the start of a round executes one iLQR iteration
       stats.converged_solves += hc[1];
       stats.batch_iterations++; ++rounds_this_solve;
+      // "debug" (ilqr.hpp:45,79-80,262-267) at batch granularity: one line per round instead of one per agent and iteration
+      if (debug) std::cout << "iLQR batch iter " << r << ": active=" << n_before << " still_active=" << n_after << " converged=" << hc[1] << '\n';
       be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_before));
       for (size_t q = marks[r & 1].s0; q < marks[r & 1].s1; ++q) stamp_launches[q].bytes *= static_cast<double>(n_before);
       n_before = n_after;
