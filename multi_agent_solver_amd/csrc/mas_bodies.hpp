@@ -193,7 +193,16 @@ struct ForwardBody {
   ALView al;
   MAS_HD void operator()(int a, int j) const {
     constexpr int NX = M::NX, NU = M::NU;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // A wavefront with at least one active agent rolls out ALL its 64 agents: a retired agent's lane costs nothing
+    // extra (SIMD), its results go to its own unused trial slots and trial_merit entry (SelectBody ignores inactive
+    // agents) -- but every store of the wavefront then covers whole 128-byte lines.  With the retired lanes masked
+    // off the same stores are partial-line writes whose acknowledgements take so long that the in-order memory
+    // counter throttles the wavefront: measured 373 us instead of 154 us per launch once few agents are active.
+    if (__ballot(active[a] != 0) == 0ull) return;
+#else
     if (!active[a]) return;
+#endif
     double alpha = 1.0;
     for (int q = 0; q < j; ++q) alpha *= 0.5;
     double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
