@@ -240,7 +240,6 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
   const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
   auto fetch = [&]() { MAS_UNROLL for (int c = 0; c < NCH; ++c) pre[c] = ld_off(tiles_t, fetch_off[c]); };
-  fetch();
   long long regs = 0;
   // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
   // reference's `reg *= 10.0`) for the q < lane rungs it has to apply, -0.0 (adds nothing, changes no bit) after
@@ -259,6 +258,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   }
   double* kff_t = kff + static_cast<size_t>(d.T - 1) * NU * d.Np;
   double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
+  fetch();
 
   for (int t = d.T - 1; t >= 0; --t, kff_t -= static_cast<size_t>(NU) * d.Np, Kfb_t -= static_cast<size_t>(NU) * NX * d.Np) {
     MAS_UNROLL for (int c = 0; c < NCH; ++c) lds[publish_at[c]] = pre[c];
@@ -353,7 +353,10 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int q = 0; q < NU; ++q) s += ninv[q * NU + m] * qu[q];
         kf[m] = s;
       }
-      if (valid && lane == 0) { MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]); }
+      // gain stores are unconditional straight-line code: every lane of an agent holds the same k (and every lane
+      // with the same i the same K column), so the duplicates write identical bits to identical addresses, and an
+      // idle slot writes into the unused gain rows of its retired agent: no divergent branch, no exec juggling.
+      MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
 
       constexpr int RM = (NX * NX + LPA - 1) / LPA;                  // rounds over the v_xx entries
       MAS_UNROLL for (int r = 0; r < RM; ++r) {
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
           vxi = vxi + s;
           const bool owner = live && j == 0;
           T[owner ? (TL::oVx + i) : TL::oDummy] = vxi;
-          if (owner) { MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[r][m], Ki[m]); }
+          MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[r][m], Ki[m]);
         }
       }
     }
