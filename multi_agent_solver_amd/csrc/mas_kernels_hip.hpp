@@ -260,7 +260,11 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
   fetch();
 
-  for (int t = d.T - 1; t >= 0; --t, kff_t -= static_cast<size_t>(NU) * d.Np, Kfb_t -= static_cast<size_t>(NU) * NX * d.Np) {
+  // one time step.  The first step is peeled off the loop so that the loop is entered in the state its back edge
+  // has -- tile loads issued, then the gain stores of a step -- and the wait for the tile at the head of the loop can
+  // let the younger stores stay in flight (s_waitcnt vmcnt(#stores)); entered from straight-line code the compiler has
+  // to wait for vmcnt(0) there, which puts every step's store acknowledgements on the serial chain.
+  auto step = [&](int t) {
     MAS_UNROLL for (int c = 0; c < NCH; ++c) lds[publish_at[c]] = pre[c];
     if (t > 0) tiles_t -= step_doubles;              // uniform; at t == 0 the (unused) prefetch re-reads step 0
     MAS_UNROLL for (int c = 0; c < NCH; ++c) MAS_OPAQUE32(fetch_off[c]);
@@ -411,7 +415,10 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       }
     }
     // the barrier after the next publish orders these writes before pass 1 reads them
-  }
+    kff_t -= static_cast<size_t>(NU) * d.Np; Kfb_t -= static_cast<size_t>(NU) * NX * d.Np;
+  };
+  step(d.T - 1);
+  for (int t = d.T - 2; t >= 0; --t) step(t);
   if (valid && lane == 0) reg_events[a] += regs;
 }
 
