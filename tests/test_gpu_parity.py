@@ -103,6 +103,21 @@ def test_edge_cases_ragged_and_tiny(gpu_lib, oracle):
         _same(e, o)
 
 
+@pytest.mark.parametrize("strategy,outer", [("sequential", 4), ("trustregion", 3)])
+def test_perturbed_agents_converge_at_different_rounds(gpu_lib, oracle, strategy, outer):
+    """SURVEY 8(d) robustness variant: x0 perturbed by a seeded N(0, 0.1^2), so agents are not rotations of one
+    another and retire in different rounds -- mixed wavefronts for the compacted sweep, the chained solves of the
+    sequential strategy and the whole-wavefront forward pass; random warm-start controls on top."""
+    N, T = 300, 60
+    rng = np.random.default_rng(0)
+    x0 = oracle.single_track_x0(N) + 0.1 * rng.standard_normal((N, 4))
+    U0 = 0.05 * rng.standard_normal((N, T, 2))
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, U0, T, 0.5, strategy, max_outer=outer)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, U0, T, 0.5, strategy=strategy, max_outer=outer)
+    _same(e, o)
+    assert len(set(o["iters"].tolist())) > 3          # the agents really do finish at different times
+
+
 def test_golden_fixtures_on_the_gpu(gpu_lib):
     """the committed (oracle-generated, det-trig) vectors, without running the oracle"""
     import importlib.util
