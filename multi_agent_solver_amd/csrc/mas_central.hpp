@@ -9,8 +9,10 @@
 //   * termination (improvement of that merit),
 //   * the regularisation ladder: LLT of the block-diagonal q_uu fails if ANY block fails, and
 //     reg*I is then added to EVERY block (ilqr.hpp:172-182).
-// The ladder needs an any-agent reduction per time step, so the backward pass runs as ONE
-// workgroup (<= 1024 agents = 16 wavefronts) with a barrier-reduction per rung.
+// The ladder needs an all-agents agreement per time step.  On the GPU the backward pass is the 16-lane tile kernel
+// (mas_kernels_hip.hpp, SharedLadder) with a counter-based agreement across its <= 256 resident wavefronts
+// (LadderSync); CentralBackwardBody below -- ONE workgroup, one lane per agent, a barrier-reduction per rung -- is
+// the statement the host emulation replays and the path of the constrained test models.
 #pragma once
 
 #include "mas_bodies.hpp"

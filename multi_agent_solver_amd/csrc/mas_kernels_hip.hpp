@@ -168,10 +168,59 @@ struct BackwardTileLayout {
 //            registers: each lane rebuilds the two gain columns and the two rows of K^T q_uu it needs,
 //            evaluates its own and its mirror entry of v_xx and applies the reference's aliased
 //            in-place symmetrisation rule, so no further exchange is needed.
-template <class M, int LPA>
+// Rung agreement of the centralised strategy (SharedLadder): the stacked q_uu is block-diagonal, its LLT fails if
+// ANY block fails and reg*I is then added to EVERY block (ilqr.hpp:172-182), so all agents use the first rung at
+// which all of them succeed.  Per (time step, chunk of 16 rungs) there are three 64-bit words; every wavefront adds
+// to each of them, with ONE fire-and-forget atomic, 1 to an arrival counter (bits 54..62) and 1 to the 9-bit
+// counter of every rung of that word at which one of its agents failed (six rungs per word), then polls the three
+// words until each arrival counter shows all wavefronts: a rung is agreed on when its failure counter is zero.
+// Every word carries its own arrival counter because the three atomics may complete in any order.  Cost: one
+// atomic flight plus one or two polls per time step, no fence.  The launch is at most 256 single-wavefront
+// workgroups (1024 agents), all resident at once, so the wait always ends; it is bounded anyway (a wavefront that
+// gives up raises *error, every later wait returns at once, and the host reports it).
+struct LadderSync {
+  unsigned long long* words = nullptr;   // [T * kChunks][4] (three used), preset to zero
+  int* error = nullptr;
+  static constexpr int kChunks = 32, kRungsPerWord = 6, kFieldBits = 9, kArrivalShift = 54;
+};
+__device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned wave_ok_mask, int n_waves) {
+  unsigned agreed = 0u;
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* w = sy.words + static_cast<size_t>(slot) * 4;
+    const unsigned fail = ~wave_ok_mask & 0xFFFFu;
+    MAS_UNROLL for (int k = 0; k < 3; ++k) {
+      unsigned long long add = 1ull << LadderSync::kArrivalShift;
+      MAS_UNROLL for (int i = 0; i < LadderSync::kRungsPerWord; ++i) {
+        const int r = k * LadderSync::kRungsPerWord + i;
+        if (r < 16 && ((fail >> r) & 1u)) add += 1ull << (LadderSync::kFieldBits * i);
+      }
+      atomicAdd(w + k, add);
+    }
+    unsigned long long v[3] = {0ull, 0ull, 0ull};
+    int spins = 0;
+    for (;;) {
+      bool all = true;
+      MAS_UNROLL for (int k = 0; k < 3; ++k) {
+        v[k] = __atomic_load_n(w + k, __ATOMIC_RELAXED);
+        all = all && static_cast<int>((v[k] >> LadderSync::kArrivalShift) & 0x1FFull) == n_waves;
+      }
+      if (all) break;
+      if (++spins > (1 << 18) || __atomic_load_n(sy.error, __ATOMIC_RELAXED) != 0) { atomicExch(sy.error, 1); break; }   // ~0.3 s, once per launch
+      __builtin_amdgcn_s_sleep(1);
+    }
+    MAS_UNROLL for (int r = 0; r < 16; ++r) {
+      const unsigned long long f = (v[r / LadderSync::kRungsPerWord] >> (LadderSync::kFieldBits * (r % LadderSync::kRungsPerWord))) & 0x1FFull;
+      if (f == 0ull) agreed |= 1u << r;
+    }
+  }
+  return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(agreed)));
+}
+
+template <class M, int LPA, bool SharedLadder = false>
 __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
                                                                double* __restrict__ kff, double* __restrict__ Kfb,
-                                                               long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n) {
+                                                               long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n,
+                                                               LadderSync sync) {
   using TL = BackwardTileLayout<M>;
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
@@ -183,7 +232,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
   const int a0 = lo + blockIdx.x * APW, a = a0 + slot;
   const bool valid = (a < n) && active[a] != 0;
-  if (__ballot(valid) == 0ull) return;              // uniform for the (single-wave) block
+  if (!SharedLadder && __ballot(valid) == 0ull) return;   // uniform for the (single-wave) block; a shared ladder needs every wavefront
   double* T = lds + slot * TL::STRIDE;
 
   if (!valid) {                                     // idle slot: finite operands (its lanes run the same code, results unused)
@@ -313,9 +362,27 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
           MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += rung_add[q];
         }
+        int win = -1;
+        if constexpr (SharedLadder) {
+          // all agents of the launch move through the ladder together, 16 rungs per agreement
+          double reg_next = 0.0;
+          for (int base = 0, chunk = 0;; base += LL, ++chunk) {
+            if (chunk > 0) {
+              if (chunk == 1) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+              for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
+            }
+            MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
+            const int ok = llt_compute<NU>(Lfac) == 0;
+            unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (!valid) field = 0xFFFFu;                                   // an idle slot never holds the others back
+            MAS_UNROLL for (int sh = LPA; sh < 64; sh <<= 1) field &= static_cast<unsigned>(__shfl_xor(static_cast<int>(field), sh));
+            const unsigned agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
+            if (agreed != 0u) { win = base + __builtin_ctz(agreed); break; }
+            if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; break; }   // guard, never reached (see kRegLadderMax)
+          }
+        } else {
         // rungs 0..15 first, as straight-line code (three out of four steps need no regularisation at all and
         // the rest settle within 15 rungs on every workload of this repository) ...
-        int win = -1;
         {
           MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
           const int ok = llt_compute_straight<NU>(Lfac) == 0;
@@ -345,8 +412,9 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
             }
           }
         }
+        }
         if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oAtV + i] = Lfac[i]; }   // oAtV is dead after pass 2
-        if (lane == 0) regs += win;
+        if (lane == 0 && (!SharedLadder || a == 0)) regs += win;         // the stacked solve counts its rungs once (agent 0)
         __syncthreads();
         MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oAtV + i];
       }

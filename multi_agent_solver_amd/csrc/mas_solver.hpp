@@ -259,13 +259,12 @@ class SolverImpl final : public SolverBase {
       const double nact = static_cast<double>(d.N);
       stats.agent_iterations += d.N;
       launch_sweep(sweep_bytes() * nact);
-      if (!Dsoa) Dsoa = dalloc(static_cast<size_t>(d.T) * L::ND * d.Np);
-      be.template launch_2d<4>("tiles_to_soa", TilesToSoaBody{d, L::ND, D, Dsoa}, d.N, d.T);
-      be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, Dsoa}, d.N, backward_bytes() * nact);
+      launch_central_backward(backward_bytes() * nact);
       be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       be.d2h(host_central, central, sizeof(CentralState));
+      check_ladder_sync();
       stats.batch_iterations++;
       if (host_central->done) { exit_reason = kExitConverged; break; }
     }
@@ -396,6 +395,28 @@ class SolverImpl final : public SolverBase {
     be.end();
 #endif
   }
+  // backward pass of the stacked problem: the 16-lane tile kernel with the rung agreement across all wavefronts
+  // (LadderSync); constrained models and the host emulation keep the one-workgroup body
+  void launch_central_backward(double bytes) {
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (!kConstrained) {
+      const size_t words = static_cast<size_t>(d.T) * LadderSync::kChunks * 4;
+      if (!ladder_sync) ladder_sync = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * (words + 2)));
+      MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
+      const LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
+      constexpr int apw = 64 / kBackwardLanesPerAgent;
+      be.begin("central_backward", bytes);
+      be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true>, dim3((d.N + apw - 1) / apw), dim3(64), d, P, X, D, kff, Kfb,
+                       reg_events, active, 0, static_cast<int>(d.N), sy);
+      be.end();
+      ladder_error_pending = true;
+      return;
+    }
+#endif
+    if (!Dsoa) Dsoa = dalloc(static_cast<size_t>(d.T) * L::ND * d.Np);
+    be.template launch_2d<4>("tiles_to_soa", TilesToSoaBody{d, L::ND, D, Dsoa}, d.N, d.T);
+    be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, Dsoa}, d.N, bytes);
+  }
   // backward Riccati pass: 16 lanes per agent over LDS tiles on the GPU, scalar body in the emulation
   void launch_backward(double bytes) { launch_backward(bytes, 0, d.N); }
   void launch_backward(double bytes, int lo, int hi) {
@@ -408,7 +429,7 @@ class SolverImpl final : public SolverBase {
     }
     be.begin("backward", bytes);
     constexpr int apw = 64 / kBackwardLanesPerAgent;
-    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent>, dim3((hi - lo + apw - 1) / apw), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi);
+    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false>, dim3((hi - lo + apw - 1) / apw), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi, LadderSync{});
     be.end();
 #endif
   }
@@ -555,6 +576,15 @@ class SolverImpl final : public SolverBase {
   void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); } else be.h2d(stage, src, sizeof(double) * n); }
   void download(double* dst, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(dst, stage, sizeof(double) * n); be.sync(); } else be.d2h(dst, stage, sizeof(double) * n); }
   void* raw_alloc(size_t bytes) { void* p = be.alloc(bytes); allocations.push_back(p); return p; }   // freed by the destructor
+  void check_ladder_sync() {
+#if !defined(MAS_HOST_EMULATION)
+    if (!ladder_error_pending || !ladder_sync) return;
+    ladder_error_pending = false;
+    int err = 0;
+    be.d2h(&err, ladder_sync + static_cast<size_t>(d.T) * LadderSync::kChunks * 4, sizeof(int));
+    if (err) throw std::runtime_error("centralised backward pass: a wavefront gave up waiting for the rung agreement");
+#endif
+  }
   double* dalloc(size_t n) { void* p = be.alloc(sizeof(double) * n); allocations.push_back(p); return static_cast<double*>(p); }
   int* ialloc(size_t n) { void* p = be.alloc(sizeof(int) * n); allocations.push_back(p); return static_cast<int*>(p); }
 
@@ -567,6 +597,7 @@ class SolverImpl final : public SolverBase {
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   int *live_list = nullptr, *live_count0 = nullptr;   // agents still active, compacted by select; count of round 0 (= N)
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
+  unsigned long long* ladder_sync = nullptr; bool ladder_error_pending = false;   // rung agreement of the centralised backward pass (LadderSync)
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
   CentralState *central = nullptr, *host_central = nullptr;
