@@ -83,48 +83,61 @@ MAS_DT_FN double mas_dt_kcos(double x, double y) {
 }
 
 /* Arguments outside the reduction range (|x| > 1.6e6), NaN and Inf give NaN: a loud, and still
- * reproducible, answer.  The functions are branch-free (selects only) so that a compiler can
- * merge identical sub-expressions across the many perturbed evaluations of a finite-difference
- * sweep. */
+ * reproducible, answer.  The functions are branch-free so that a compiler can merge identical
+ * sub-expressions across the many perturbed evaluations of a finite-difference sweep, and they are written
+ * for a machine on which every instruction of a dependent chain costs the same (a lone GPU wavefront):
+ *  - an out-of-range argument is reduced as 0 (so the quadrant arithmetic stays defined) and turns the
+ *    reduced argument into NaN by ADDING a poison term, -0.0 for an argument in range -- y + (-0.0) is y bit for
+ *    bit, for every y including both zeros -- so no result needs a select of its own;
+ *  - a quadrant's sign change is an exclusive-or on the sign bit (what negation is), driven by integer
+ *    arithmetic on n instead of compare-and-select. */
 MAS_DT_FN int mas_dt_in_range(double x) { return fabs(x) <= MAS_DT_MAX_ARG; } /* false for NaN */
 
-MAS_DT_FN double mas_dt_sin(double x) {
+MAS_DT_FN double mas_dt_flip_sign(double v, unsigned flip /* bit 0 */) {
+  unsigned long long u;
+  __builtin_memcpy(&u, &v, sizeof u);
+  u ^= (unsigned long long)(flip & 1u) << 63;
+  __builtin_memcpy(&v, &u, sizeof v);
+  return v;
+}
+
+/* reduction shared by all entry points: quadrant n, reduced argument y0 (NaN when x is out of range), tail y1 */
+MAS_DT_FN unsigned mas_dt_reduce(double x, double* y0, double* y1) {
   const int ok = mas_dt_in_range(x);
+  const unsigned n = (unsigned)mas_dt_rem_pio2(ok ? x : 0.0, y0, y1);
+  *y0 += ok ? -0.0 : (double)NAN;
+  return n;
+}
+
+MAS_DT_FN double mas_dt_sin(double x) {
   double y0, y1;
-  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
-  const double r = (n & 1) ? mas_dt_kcos(y0, y1) : mas_dt_ksin(y0, y1);
-  const double v = (n & 2) ? -r : r;
-  return ok ? v : (double)NAN;
+  const unsigned n = mas_dt_reduce(x, &y0, &y1);
+  const double r = (n & 1u) ? mas_dt_kcos(y0, y1) : mas_dt_ksin(y0, y1);
+  return mas_dt_flip_sign(r, n >> 1);
 }
 
 MAS_DT_FN double mas_dt_cos(double x) {
-  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
-  const double r = (n & 1) ? mas_dt_ksin(y0, y1) : mas_dt_kcos(y0, y1);
-  const double v = ((n + 1) & 2) ? -r : r;
-  return ok ? v : (double)NAN;
+  const unsigned n = mas_dt_reduce(x, &y0, &y1);
+  const double r = (n & 1u) ? mas_dt_ksin(y0, y1) : mas_dt_kcos(y0, y1);
+  return mas_dt_flip_sign(r, (n + 1u) >> 1);
 }
 
 /* both at once (one reduction); bitwise equal to mas_dt_sin / mas_dt_cos */
 MAS_DT_FN void mas_dt_sincos(double x, double* sn, double* cs) {
-  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
+  const unsigned n = mas_dt_reduce(x, &y0, &y1);
   const double s = mas_dt_ksin(y0, y1), c = mas_dt_kcos(y0, y1);
-  const double rs = (n & 1) ? c : s, rc = (n & 1) ? s : c;
-  const double vs = (n & 2) ? -rs : rs, vc = ((n + 1) & 2) ? -rc : rc;
-  *sn = ok ? vs : (double)NAN;
-  *cs = ok ? vc : (double)NAN;
+  const double rs = (n & 1u) ? c : s, rc = (n & 1u) ? s : c;
+  *sn = mas_dt_flip_sign(rs, n >> 1);
+  *cs = mas_dt_flip_sign(rc, (n + 1u) >> 1);
 }
 
 MAS_DT_FN double mas_dt_tan(double x) {
-  const int ok = mas_dt_in_range(x);
   double y0, y1;
-  const int n = mas_dt_rem_pio2(ok ? x : 0.0, &y0, &y1);
+  const unsigned n = mas_dt_reduce(x, &y0, &y1);
   const double s = mas_dt_ksin(y0, y1), c = mas_dt_kcos(y0, y1);
-  const double v = (n & 1) ? -(c / s) : s / c;
-  return ok ? v : (double)NAN;
+  return (n & 1u) ? -(c / s) : s / c;
 }
 
 #endif /* MAS_DETTRIG_H */
