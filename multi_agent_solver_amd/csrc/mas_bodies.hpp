@@ -216,31 +216,35 @@ struct ForwardBody {
     const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np, sK = static_cast<size_t>(NU) * NX * d.Np;
     const double *Xt = X, *Ut = U, *kt = kff, *Kt = Kfb;
     double *Xjt = Xj, *Ujt = Uj;
-    // reference point and gains of step t+1 are requested before step t is integrated (software pipeline)
-    double xr[NX], ur[NU], k[NU], K[NU * NX], xr_n[NX], ur_n[NU], k_n[NU], K_n[NU * NX];
+    // reference point and gains of step t+1 are requested before step t is integrated (software pipeline); the two
+    // operand sets swap roles from one step to the next (loop unrolled by two), so nothing is copied between them
+    struct Operands { double xr[NX], ur[NU], k[NU], K[NU * NX]; };
+    Operands opA, opB;
+    auto request = [&](Operands& o) {
+      MAS_UNROLL for (int i = 0; i < NX; ++i) o.xr[i] = ld_off(Xt, off[i]);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) o.ur[i] = ld_off(Ut, off[i]);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) o.k[i] = ld_off(kt, off[i]);
+      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) o.K[i] = ld_off(Kt, off[i]);
+    };
     MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = ld_off(x0, off[i]); st_off(Xjt, off[i], x[i]); }
-    MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = ld_off(Xt, off[i]);
-    MAS_UNROLL for (int i = 0; i < NU; ++i) ur[i] = ld_off(Ut, off[i]);
-    MAS_UNROLL for (int i = 0; i < NU; ++i) k[i] = ld_off(kt, off[i]);
-    MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = ld_off(Kt, off[i]);
+    request(opA);
     double c = 0.0;
-    for (int t = 0; t < d.T; ++t) {
+    double lbv[NU], ubv[NU];                                         // the bounds, kept in vector registers for the selects
+    MAS_UNROLL for (int i = 0; i < NU; ++i) { lbv[i] = lb[i]; ubv[i] = ub[i]; MAS_VGPR64(lbv[i]); MAS_VGPR64(ubv[i]); }
+    auto step = [&](int t, const Operands& cur, Operands& next) {
       if (t + 1 < d.T) { Xt += sX; Ut += sU; kt += sU; Kt += sK; }   // uniform
       MAS_UNROLL for (int i = 0; i < NR; ++i) MAS_OPAQUE32(off[i]);
-      MAS_UNROLL for (int i = 0; i < NX; ++i) xr_n[i] = ld_off(Xt, off[i]);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) ur_n[i] = ld_off(Ut, off[i]);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) k_n[i] = ld_off(kt, off[i]);
-      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K_n[i] = ld_off(Kt, off[i]);
-      forward_control<M>(x, xr, ur, k, K, alpha, clamp, lb, ub, u);
+      request(next);
+      forward_control<M>(x, cur.xr, cur.ur, cur.k, cur.K, alpha, clamp, lbv, ubv, u);
       MAS_UNROLL for (int i = 0; i < NU; ++i) st_off(Ujt, off[i], u[i]);
       c += M::stage_cost(x, u, t, P);
       rk4_step<M>(x, u, dt, xn, P);
       Xjt += sX; Ujt += sU;
       MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; st_off(Xjt, off[i], x[i]); }
-      MAS_UNROLL for (int i = 0; i < NX; ++i) xr[i] = xr_n[i];
-      MAS_UNROLL for (int i = 0; i < NU; ++i) { ur[i] = ur_n[i]; k[i] = k_n[i]; }
-      MAS_UNROLL for (int i = 0; i < NU * NX; ++i) K[i] = K_n[i];
-    }
+    };
+    int t = 0;
+    for (; t + 1 < d.T; t += 2) { step(t, opA, opB); step(t + 1, opB, opA); }
+    if (t < d.T) step(t, opA, opB);
     c += M::terminal_cost(x, P);
     double m = c;
     if constexpr (M::NEQ + M::NIN > 0) {

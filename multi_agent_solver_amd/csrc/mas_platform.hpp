@@ -22,8 +22,12 @@
 // LICM hoists the zero-extension to 64 bits out of the loop and instruction selection no longer sees
 // "uniform base + zext(32-bit lane offset)", so every access pays a v_lshl_add_u64 (and a hazard nop)
 // instead of using the scalar-base addressing form  global_load v, v_off32, s[base:base+1].
+// MAS_VGPR64(v): pins a loop-invariant double (a kernel argument) in a vector register pair before a loop, so a
+// select that uses it needs no per-use copy from scalar registers.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAS_OPAQUE32(v) asm volatile("" : "+v"(v))
+#define MAS_VGPR64(v) asm volatile("" : "+v"(v))
 #else
 #define MAS_OPAQUE32(v) ((void)0)
+#define MAS_VGPR64(v) ((void)0)
 #endif
