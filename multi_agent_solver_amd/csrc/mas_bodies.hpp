@@ -236,11 +236,11 @@ struct ForwardBody {
       MAS_UNROLL for (int i = 0; i < NR; ++i) MAS_OPAQUE32(off[i]);
       request(next);
       forward_control<M>(x, cur.xr, cur.ur, cur.k, cur.K, alpha, clamp, lbv, ubv, u);
-      MAS_UNROLL for (int i = 0; i < NU; ++i) st_off(Ujt, off[i], u[i]);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) { MAS_OPAQUE32(off[i]); st_off(Ujt, off[i], u[i]); }
       c += M::stage_cost(x, u, t, P);
       rk4_step<M>(x, u, dt, xn, P);
       Xjt += sX; Ujt += sU;
-      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; st_off(Xjt, off[i], x[i]); }
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_OPAQUE32(off[i]); st_off(Xjt, off[i], x[i]); }
     };
     int t = 0;
     for (; t + 1 < d.T; t += 2) { step(t, opA, opB); step(t + 1, opB, opA); }
