@@ -279,6 +279,16 @@ struct SelectBody {
   double* improvement_out = nullptr;   // non-null: termination is decided by ALUpdateBody after the multiplier update
   int* next_list = nullptr;            // non-null: the agents still active, compacted (slot = value of n_active when it was counted)
   int* solves_left = nullptr;          // non-null: an agent whose solve ends starts its next one at once (chained solves, see begin_chain)
+  // per-solve wall-clock budget, ilqr.hpp:61,84-90: non-null = max_ms is finite; solve_start[a] is the tick at which agent
+  // a's current solve began.  The reference checks `elapsed_ms > max_ms` (elapsed truncated to whole ms) at the top of every
+  // iteration; here the check for iteration i+1 is made at the end of iteration i (select), a few microseconds earlier.
+  unsigned long long* solve_start = nullptr; double max_ms = 0.0;
+  int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // "debug" trace: iteration number (0 = idle) and d_merit per agent
+  MAS_HD bool out_of_time(int a) const {
+    if (!solve_start) return false;
+    const double elapsed_ms = static_cast<double>(static_cast<long long>(static_cast<double>(MAS_NOW_TICKS() - solve_start[a]) / kTicksPerMs));
+    return elapsed_ms > max_ms;
+  }
   // what became of agent a in this iteration; bit 2 = its solve ended but it goes straight on with its next solve
   enum Outcome { kIdle = 0, kStillActive = 1, kConverged = 2, kRetired = 3, kChained = 4 };
   // detail::run_sequential (nash.hpp:74-90) calls solve() on every agent max_outer times, and an agent's solve k+1
@@ -288,11 +298,12 @@ struct SelectBody {
   MAS_HD bool begin_chain(int a) const {
     if (!solves_left || solves_left[a] <= 0) return false;
     solves_left[a] -= 1; iters_solve[a] = 0;
+    if (solve_start) solve_start[a] = MAS_NOW_TICKS();      // const auto start = clock::now(), ilqr.hpp:61
     return true;
   }
   MAS_HD int decide(int a) const {
     if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
-    if (!active[a]) { alpha_sel[a] = -1; return kIdle; }
+    if (!active[a]) { alpha_sel[a] = -1; if (dbg_iter) dbg_iter[a] = 0; return kIdle; }
     const double cur = merit[a];
     int sel = -1; double best = cur;
     for (int j = 0; j < kNumAlphas; ++j) {
@@ -304,6 +315,7 @@ struct SelectBody {
     if (sel >= 0) { cost[a] = trial_obj ? trial_obj[static_cast<size_t>(sel) * d.Np + a] : best; merit[a] = best; }   // cost = objective(best_x,best_u); current_merit = best_merit
     const int it = iters_solve[a] + 1;
     iters_solve[a] = it; iters_total[a] += 1;
+    if (dbg_iter) { dbg_iter[a] = it; dbg_improvement[a] = improvement; }
     if (improvement_out) { improvement_out[a] = improvement; return kIdle; }
     if (improvement < tolerance) {                          // ilqr.hpp:269-271
       exit_code[a] = kExitConverged | (std::isfinite(best) ? 0 : kExitNonFinite);
@@ -313,6 +325,12 @@ struct SelectBody {
     }
     if (it >= max_iterations) {                             // ilqr.hpp:82
       exit_code[a] = kExitMaxIter | (std::isfinite(best) ? 0 : kExitNonFinite);
+      if (begin_chain(a)) return kRetired | kChained;
+      active[a] = 0;
+      return kRetired;
+    }
+    if (out_of_time(a)) {                                   // ilqr.hpp:84-90, top of the next iteration
+      exit_code[a] = kExitTime | (std::isfinite(best) ? 0 : kExitNonFinite);
       if (begin_chain(a)) return kRetired | kChained;
       active[a] = 0;
       return kRetired;
@@ -366,6 +384,7 @@ struct ALUpdateBody {
   const double* X; const double* U; const double* improvement;
   ALView al;
   int* active; const int* iters_solve; int* exit_code; int* n_active; long long* n_converged;
+  const unsigned long long* solve_start = nullptr; double max_ms = 0.0;     // finite per-solve budget (see SelectBody)
   MAS_HD void operator()(int a) const {
     constexpr int NX = M::NX, NU = M::NU;
     if (!active[a]) return;
@@ -389,6 +408,8 @@ struct ALUpdateBody {
       MAS_ATOMIC_ADD_I64(n_converged, 1LL);
     } else if (iters_solve[a] >= max_iterations) {
       active[a] = 0; exit_code[a] = kExitMaxIter;
+    } else if (solve_start && static_cast<double>(static_cast<long long>(static_cast<double>(MAS_NOW_TICKS() - solve_start[a]) / kTicksPerMs)) > max_ms) {
+      active[a] = 0; exit_code[a] = kExitTime;
     } else {
       MAS_ATOMIC_ADD_INT(n_active, 1);
     }
@@ -403,8 +424,10 @@ struct BeginSolveBody {
   long long* counters = nullptr; int n_counters = 0;           // the round counters of the solve, zeroed by agent 0
   int* live_list = nullptr; int* live_count = nullptr; int n_agents = 0;   // every agent is active: identity list
   int* solves_left = nullptr; int chained = 0;                 // further solves every agent runs back to back after this one
+  unsigned long long* solve_start = nullptr;                   // non-null: finite max_ms, stamp the start of the solve (ilqr.hpp:61)
   MAS_HD void operator()(int a) const {
     active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1;
+    if (solve_start) solve_start[a] = MAS_NOW_TICKS();
     if (solves_left) solves_left[a] = chained;
     if (merit) merit[a] = cost[a];
     if (live_list) live_list[a] = a;

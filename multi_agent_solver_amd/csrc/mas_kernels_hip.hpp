@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, c
     dst_full[k] = (A < 0) ? -1 : (A >> 6) * 64 * ND + (A & 63) * CH + (lane & (CH - 1));
   }
   MAS_UNROLL for (int k = 0; k < REM; ++k) {
-    const int idx = k * 64 + lane, ag = idx / REM, e = idx - ag * REM;
+    constexpr int REMD = REM > 0 ? REM : 1;                          // (the loop has no trips when REM == 0)
+    const int idx = k * 64 + lane, ag = idx / REMD, e = idx - ag * REMD;
     const int A = slot_agent[w][ag];
     dst_rem[k] = (A < 0) ? -1 : (A >> 6) * 64 * ND + NFULL * CH * 64 + (A & 63) * REM + e;
   }

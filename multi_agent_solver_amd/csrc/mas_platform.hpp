@@ -18,6 +18,18 @@
 #define MAS_UNROLL _Pragma("unroll")
 #endif
 
+// mas_now_ticks(): free-running clock in 10-ns ticks (100-MHz REFCLK on the device, steady_clock in the emulation); the
+// per-solve wall-clock budget `max_ms` (ilqr.hpp:84-90) is measured with it on the device, one start stamp per agent
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAS_NOW_TICKS() static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime())
+#elif defined(MAS_HOST_EMULATION)
+#include <chrono>
+#define MAS_NOW_TICKS() static_cast<unsigned long long>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10)
+#else
+#define MAS_NOW_TICKS() 0ull
+#endif
+constexpr double kTicksPerMs = 1e5;
+
 // MAS_OPAQUE32(v): hides a loop-invariant 32-bit byte offset from the optimiser inside a loop.  Without it
 // LICM hoists the zero-extension to 64 bits out of the loop and instruction selection no longer sees
 // "uniform base + zext(32-bit lane offset)", so every access pays a v_lshl_add_u64 (and a hazard nop)

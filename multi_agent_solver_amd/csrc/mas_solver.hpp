@@ -174,8 +174,7 @@ class SolverImpl final : public SolverBase {
   void restore_initial() override {
     require(saved, "no saved initial state");
     be.d2d(x0, x0_saved, sizeof(double) * NX * d.Np); be.d2d(U, U_saved, sizeof(double) * d.T * NU * d.Np);
-    { std::vector<long long> rg(d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N); for (auto v : rg) reg_base += v; }
-    be.zero(iters_total, sizeof(int) * d.Np); be.zero(reg_events, sizeof(long long) * d.Np);   // per-agent counters restart with the problem
+    be.zero(iters_total, sizeof(int) * d.Np);   // per-agent iteration counts restart with the problem; reg_events keeps counting since reset_stats (no read-back here)
     have_x0 = true;
     initialize_problem();
   }
@@ -189,9 +188,9 @@ class SolverImpl final : public SolverBase {
     ensure_initialized();
     // update_initial_with_best (nash.hpp:66-71) has no device-side effect, and an agent's solve k+1 depends only on
     // its own solve k: the max_outer solves of every agent run back to back in one stream of rounds (no host
-    // barrier between outer iterations).  A wall-clock budget per solve (max_ms) or the multiplier update between
-    // solves needs the host between them, so those cases keep the loop.
-    const bool chain = max_outer > 1 && !(kConstrained && al_enabled) && !(max_ms < std::numeric_limits<double>::infinity());
+    // barrier between outer iterations); a finite max_ms is honoured per solve by start stamps on the device.  The
+    // multiplier update between solves and the per-agent debug trace need the host between them and keep the loop.
+    const bool chain = max_outer > 1 && !(kConstrained && al_enabled) && !debug;
     if (chain) solve_all(max_outer);
     else for (int outer = 0; outer < max_outer; ++outer) solve_all();
     last_total_valid = false;
@@ -288,6 +287,7 @@ class SolverImpl final : public SolverBase {
   void debug_backward(double* derivs, double* ko, double* Ko, int64_t* regs) override {
     ensure_initialized();
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
+    { std::vector<long long> rg(d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N); for (auto v : rg) reg_base += v; }   // keep the running statistics
     be.zero(reg_events, sizeof(long long) * d.Np);
     launch_sweep(0.0);
     launch_backward(0.0);
@@ -360,7 +360,9 @@ class SolverImpl final : public SolverBase {
   }
 
   // algorithmic bytes per agent and launch
-  double sweep_bytes() const { return 8.0 * ((NX + NU) * d.T) + 8.0 * d.T * L::ND; }
+  // sweep: SURVEY.md section 8(d)'s figure, read 8[(nx+nu)T + nx] + write 8[T*ND + nx + nx^2] (51,392 B at (4,2,100)); this
+  // kernel itself moves 8(nx + nx + nx^2) bytes less (x_T and the terminal v_x, v_xx are handled by the backward kernel)
+  double sweep_bytes() const { return 8.0 * ((NX + NU) * d.T + NX) + 8.0 * (d.T * L::ND + NX + NX * NX); }
   double backward_bytes() const { return 8.0 * d.T * L::ND + 8.0 * NX + 8.0 * d.T * (NU + NU * NX); }
   double forward_bytes() const { return 8.0 * (d.T * (NX + NU + NU + NU * NX) + NX) + 8.0 * ((d.T + 1) * NX + d.T * NU); }
 
@@ -477,9 +479,13 @@ class SolverImpl final : public SolverBase {
     if (kConstrained && al_enabled) { sync_penalty(); rollout_consistent = false; }   // merit depends on the current multipliers
     // begin_solve also sets current_merit = compute_merit(x,u) == objective (ilqr.hpp:78) when no rollout follows,
     // and zeroes the round counters
+    // max_ms (ilqr.hpp:61,84-90): every agent's solve has its own clock, started on the device when the solve begins
+    const bool timed = max_ms < std::numeric_limits<double>::infinity();
+    if (timed && !solve_start) solve_start = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * d.Np));
+    if (debug && !dbg_iter) { dbg_iter = ialloc(d.Np); dbg_improvement = dalloc(d.Np); }
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
                                                            counters, 2 * kCounterRing, live_list, live_count0, d.N,
-                                                           solves_left, n_solves - 1}, d.N);
+                                                           solves_left, n_solves - 1, timed ? solve_start : nullptr}, d.N);
     if (!rollout_consistent) {
       be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
       rollout_consistent = true;
@@ -487,15 +493,14 @@ class SolverImpl final : public SolverBase {
     stats.solves += static_cast<long long>(d.N) * n_solves;
     const long long round_limit = static_cast<long long>(max_iterations) * n_solves;   // every solve ends after max_iterations rounds at the latest
     if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
-    if (debug) std::cout << "iLQR batch initial cost=" << host_sum(cost) << " agents=" << d.N << " solves_per_agent=" << n_solves << '\n';
-    const auto t0 = std::chrono::steady_clock::now();
+    if (debug) debug_initial();
     const ForwardBody<M> fwd = make_forward();
 #if defined(MAS_HOST_EMULATION)
     const bool run_ahead = false;
 #else
     // a solve that follows a one-round solve (the re-solves of outer rounds 2..max_outer usually are) would
     // waste its run-ahead round, so run ahead only while the previous solve needed several rounds
-    const bool run_ahead = n_solves > 1 || last_solve_rounds != 1;
+    const bool run_ahead = !debug && (n_solves > 1 || last_solve_rounds != 1);
 #endif
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
@@ -515,14 +520,15 @@ class SolverImpl final : public SolverBase {
       const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
                            al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : live_list,
-                           n_solves > 1 ? solves_left : nullptr};
+                           n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
+                           debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr};
       be.template launch_1d<1>("select", sel, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       if constexpr (kConstrained) {
         if (al_round)
           be.template launch_1d<1>("al_update", ALUpdateBody<M>{d, P, tolerance, max_iterations, ALParams{penalty_increase, constraint_tolerance, inequality_activation_tolerance},
                                                                X, U, improvement, al_view(true), active, iters_solve, exit_code,
-                                                               reinterpret_cast<int*>(ctr), ctr + 1}, d.N);
+                                                               reinterpret_cast<int*>(ctr), ctr + 1, timed ? solve_start : nullptr, max_ms}, d.N);
       }
       be.d2h_async(host_counters + 2 * (r % kCounterRing), ctr, sizeof(long long) * 2);
       be.record(round_ev[r & 1]);
@@ -530,18 +536,18 @@ class SolverImpl final : public SolverBase {
     };
     long long n_before = d.N;
     int enq = 0, rounds_this_solve = 0;
-    if (max_iterations > 0 && !timed_out(t0)) { enqueue(0); enq = 1; }
+    // the first check of a solve sees elapsed_ms == 0, so only a negative budget stops it before its first iteration
+    if (max_iterations > 0 && !(timed && 0.0 > max_ms)) { enqueue(0); enq = 1; }
     else if (max_iterations > 0) be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
     for (int r = 0; r < enq; ++r) {
-      if (run_ahead && enq == r + 1 && r + 1 < round_limit && !timed_out(t0)) { enqueue(r + 1); ++enq; }
+      if (run_ahead && enq == r + 1 && r + 1 < round_limit) { enqueue(r + 1); ++enq; }
       be.wait(round_ev[r & 1]);
       const long long* hc = host_counters + 2 * (r % kCounterRing);
       const long long n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]);
       stats.agent_iterations += n_before;           // every agent active at the start of a round executes one iLQR iteration
       stats.converged_solves += hc[1];
       stats.batch_iterations++; ++rounds_this_solve;
-      // "debug" (ilqr.hpp:45,79-80,262-267) at batch granularity: one line per round instead of one per agent and iteration
-      if (debug) std::cout << "iLQR batch iter " << r << ": active=" << n_before << " still_active=" << n_after << " converged=" << hc[1] << '\n';
+      if (debug) debug_round();
       be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_before));
       for (size_t q = marks[r & 1].s0; q < marks[r & 1].s1; ++q) stamp_launches[q].bytes *= static_cast<double>(n_before);
       n_before = n_after;
@@ -549,13 +555,29 @@ class SolverImpl final : public SolverBase {
         if (enq > r + 1) { be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0); for (size_t q = marks[(r + 1) & 1].s0; q < marks[(r + 1) & 1].s1; ++q) stamp_launches[q].bytes = 0.0; }
         break;
       }
-      if (enq == r + 1 && r + 1 < round_limit) {
-        if (timed_out(t0)) { be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N); break; }
-        enqueue(r + 1); ++enq;
-      }
+      if (enq == r + 1 && r + 1 < round_limit) { enqueue(r + 1); ++enq; }
     }
     if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);   // drain a round that ran ahead
     last_solve_rounds = rounds_this_solve;
+  }
+
+  // "debug" key (ilqr.hpp:45,79-80,262-267): the reference prints one line per solve start and one per iteration of
+  // every agent (interleaved arbitrarily across OpenMP threads); here the same lines, agent by agent after each round,
+  // prefixed with the agent's position in the batch
+  void debug_initial() {
+    std::vector<double> c(d.N), m(d.N);
+    be.d2h(c.data(), cost, sizeof(double) * d.N); be.d2h(m.data(), merit, sizeof(double) * d.N);
+    for (int a = 0; a < d.N; ++a) std::cout << "[agent " << a << "] iLQR initial cost=" << c[a] << " merit=" << m[a] << '\n';
+    std::cout.flush();
+  }
+  void debug_round() {
+    std::vector<double> c(d.N), m(d.N), imp(d.N); std::vector<int> it(d.N);
+    be.d2h(c.data(), cost, sizeof(double) * d.N); be.d2h(m.data(), merit, sizeof(double) * d.N);
+    be.d2h(imp.data(), dbg_improvement, sizeof(double) * d.N); be.d2h(it.data(), dbg_iter, sizeof(int) * d.N);
+    for (int a = 0; a < d.N; ++a)
+      if (it[a] > 0) std::cout << "[agent " << a << "] iLQR iter " << (it[a] - 1) << ": cost=" << c[a] << " merit=" << m[a] << " d_merit=" << imp[a]
+                               << " eq_violation=0 ineq_violation=0\n";
+    std::cout.flush();
   }
 
   // detail::compute_total_cost over ALL agents (nash.hpp:45-49): through the caller's exchange when the block
@@ -597,6 +619,8 @@ class SolverImpl final : public SolverBase {
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   int *live_list = nullptr, *live_count0 = nullptr;   // agents still active, compacted by select; count of round 0 (= N)
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
+  unsigned long long* solve_start = nullptr;          // tick at which each agent's current solve began (finite max_ms only)
+  int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // per-agent trace of the last round ("debug")
   unsigned long long* ladder_sync = nullptr; bool ladder_error_pending = false;   // rung agreement of the centralised backward pass (LadderSync)
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;

@@ -795,6 +795,12 @@ static double collect_total(mas_ocp** ocps, int n) {   /* collect_solution, nash
   double c = 0.0; for (int i = 0; i < n; ++i) c += ocps[i]->best_cost; return c;
 }
 
+/* optional per-agent exit reason of each agent's LAST solve (enum mas_exit_reason); the reference's solve() returns
+ * nothing (ilqr.hpp:58-273), the product reports it as an extension and the tests check it against this */
+static int* g_exit_out = NULL;
+void mas_oracle_set_exit_buffer(int* buf) { g_exit_out = buf; }
+static void report_exits(const mas_ilqr* sv, int n) { if (g_exit_out) for (int i = 0; i < n; ++i) g_exit_out[i] = sv[i].exit_reason; }
+
 static double g_al_params[4] = {10.0, 5.0, 1e-4, 1e-6};
 void mas_oracle_set_al_params(double penalty, double penalty_increase, double constraint_tolerance, double inequality_activation_tolerance) {
   g_al_params[0] = penalty; g_al_params[1] = penalty_increase; g_al_params[2] = constraint_tolerance; g_al_params[3] = inequality_activation_tolerance;
@@ -827,6 +833,7 @@ double mas_run_sequential(mas_ocp** ocps, int n, int max_outer, int max_iteratio
                  stats->reg_events += per[i].reg_events; stats->trials += per[i].trials;
                  for (int j = 0; j < 12; ++j) stats->alpha_hist[j] += per[i].alpha_hist[j]; }
   }
+  report_exits(sv, n);
   free(per); free_solvers(sv, n);
   return collect_total(ocps, n);
 }
@@ -873,6 +880,7 @@ double mas_run_trust_region(mas_ocp** ocps, int n, int max_outer, int max_iterat
                  stats->reg_events += per[i].reg_events; stats->trials += per[i].trials;
                  for (int j = 0; j < 12; ++j) stats->alpha_hist[j] += per[i].alpha_hist[j]; }
   }
+  report_exits(sv, n);
   free(per); free(radii); free_solvers(sv, n);
   return collect_total(ocps, n);
 }
@@ -934,7 +942,7 @@ double mas_run_line_search(mas_ocp** ocps, int n, int max_outer, int max_iterati
                  for (int j = 0; j < 12; ++j) stats->alpha_hist[j] += per[i].alpha_hist[j]; }
     free(old_u[i]); free(old_x[i]); free(cand_u[i]); free(tr_u[i]); free(tr_x[i]);
   }
-  free(old_u); free(old_x); free(cand_u); free(tr_u); free(tr_x); free(per); free_solvers(sv, n);
+  free(old_u); free(old_x); free(cand_u); free(tr_u); free(tr_x); report_exits(sv, n); free(per); free_solvers(sv, n);
   return collect_total(ocps, n);
 }
 

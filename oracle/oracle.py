@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
         _lib.mas_oracle_set_trig_mode.argtypes = [C.c_int]
         _lib.mas_oracle_get_trig_mode.restype = C.c_int
         _lib.mas_oracle_set_al_params.argtypes = [C.c_double] * 4
+        _lib.mas_oracle_set_exit_buffer.argtypes = [i]
         for name in ("mas_ref_case_initialize", "mas_ref_case_update_initial", "mas_ref_case_global",
                      "mas_ref_case_fd_gradient"):
             getattr(_lib, name).argtypes = [d]
@@ -128,10 +129,15 @@ def solve_batch(model_id, x0, U0, T, dt, strategy="sequential", max_outer=10, ma
     par = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
     if par is not None and par.size < 16:
         par = np.concatenate([par, np.zeros(16 - par.size)])
-    total = lib().mas_oracle_solve_batch(model_id, _p(par), N, T, float(dt), _p(x0), _p(U), _p(X), _p(cost),
-                                         iters.ctypes.data_as(C.POINTER(C.c_int)), STRATEGY[strategy], max_outer,
-                                         max_iterations, float(tolerance), float(max_ms), threads, C.byref(st))
-    return dict(X=X, U=U, cost=cost, iters=iters, total_cost=total,
+    status = np.full(N, -1, dtype=np.int32)        # exit reason of each agent's last solve; stays -1 for the centralised strategies
+    lib().mas_oracle_set_exit_buffer(status.ctypes.data_as(C.POINTER(C.c_int)))
+    try:
+        total = lib().mas_oracle_solve_batch(model_id, _p(par), N, T, float(dt), _p(x0), _p(U), _p(X), _p(cost),
+                                             iters.ctypes.data_as(C.POINTER(C.c_int)), STRATEGY[strategy], max_outer,
+                                             max_iterations, float(tolerance), float(max_ms), threads, C.byref(st))
+    finally:
+        lib().mas_oracle_set_exit_buffer(None)
+    return dict(X=X, U=U, cost=cost, iters=iters, status=status, total_cost=total,
                 stats=dict(total_iterations=st.total_iterations, converged_solves=st.converged_solves,
                            reg_events=st.reg_events, trials=st.trials, alpha_hist=list(st.alpha_hist)))
 

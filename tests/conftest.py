@@ -41,10 +41,10 @@ def product_lib():
     return _capi.load(g.build_hip())
 
 
-def run_batch(lib, model, x0, U0, T, dt, strategy, max_outer=10, max_iterations=100, tolerance=1e-5, **kw):
+def run_batch(lib, model, x0, U0, T, dt, strategy, max_outer=10, max_iterations=100, tolerance=1e-5, max_ms=math.inf, **kw):
     from multi_agent_solver_amd.batch import BatchSolver
     with BatchSolver(model, x0.shape[0], T, dt, lib=lib, **kw) as s:
-        s.set_params({"max_iterations": max_iterations, "tolerance": tolerance, "max_ms": math.inf})
+        s.set_params({"max_iterations": max_iterations, "tolerance": tolerance, "max_ms": max_ms})
         s.set_initial_states(x0)
         s.set_controls(U0)
         s.initialize_problem()

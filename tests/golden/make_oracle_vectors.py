@@ -22,7 +22,9 @@ CASES = [
     ("single_track_N8_T100_trustregion", O.MODEL_SINGLE_TRACK, 8, 100, 0.5, "trustregion", 10, 100, 1e-5),
     ("single_track_N8_T100_linesearch", O.MODEL_SINGLE_TRACK, 8, 100, 0.5, "linesearch", 10, 100, 1e-5),
     ("single_track_N8_T100_centralized", O.MODEL_SINGLE_TRACK, 8, 100, 0.5, "centralized", 1, 100, 1e-5),
+    ("single_track_N2_T10_centralized_dense", O.MODEL_SINGLE_TRACK, 2, 10, 0.5, "centralized_dense", 1, 100, 1e-5),
     ("single_track_N4_T10_centralized_dense", O.MODEL_SINGLE_TRACK, 4, 10, 0.5, "centralized_dense", 1, 100, 1e-5),
+    ("single_track_N10_T10_centralized_dense", O.MODEL_SINGLE_TRACK, 10, 10, 0.5, "centralized_dense", 1, 100, 1e-5),   # README.md:176's shape
     ("lqr_N2_T10_sequential", O.MODEL_LQR_IDENTITY, 2, 10, 0.1, "sequential", 10, 100, 1e-5),
     ("lqr_N2_T50_sequential", O.MODEL_LQR_IDENTITY, 2, 50, 0.1, "sequential", 10, 100, 1e-5),
     ("pendulum_T50_single", O.MODEL_PENDULUM, 1, 50, 0.05, "single", 1, 1000, 1e-4),

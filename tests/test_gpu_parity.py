@@ -30,6 +30,8 @@ def _same(e, o, total_exact=True):
     assert np.array_equal(e["X"], o["X"])
     assert np.array_equal(e["U"], o["U"])
     assert e["stats"]["reg_events"] == o["stats"]["reg_events"]
+    if (o["status"] >= 0).all():                    # the oracle reports exit reasons for the Nash strategies
+        assert (e["status"] & 3).tolist() == o["status"].tolist()
     if total_exact:
         assert e["total_cost"] == o["total_cost"]
     else:
@@ -139,10 +141,61 @@ def test_golden_fixtures_on_the_gpu(gpu_lib):
         assert [[float.hex(v) for v in e["X"][a, -1]] for a in range(c["N"])] == c["x_final"], name
 
 
-def test_full_size_config3_properties_and_sampled_parity(gpu_lib, oracle):
+def test_centralized_against_the_dense_stacked_goldens(gpu_lib):
+    """mas_hip_run_centralized implements the block-diagonal reading of the stacked problem; the reference
+    (centralized.hpp:18-38 on build_global_ocp, multi_agent_problem.hpp:94-122) finite-differences the SUMMED cost, so
+    its stacked Hessians carry noise in the cross-agent blocks (~14 % of l_uu at 256 agents) and
+    its answer is a different number.  Against the committed `centralized_dense` vectors (the oracle's literal stacked
+    solve) at N = 2, 4, 10, T = 10 -- tolerance: total cost 5e-3 relative, per-agent cost 1e-2 relative, same iteration
+    count (measured on the oracle pair: 2.6e-4 / 3.2e-5 / 1.3e-3 on the total, <= 4.9e-3 per agent)."""
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = json.load(open(os.path.join(here, "golden", "oracle_vectors.json")))["cases"]
+    seen = 0
+    for name, c in gold.items():
+        if c["strategy"] != "centralized_dense":
+            continue
+        seen += 1
+        x0 = np.array(c["x0"])
+        e = run_batch(gpu_lib, c["model"], x0, None, c["T"], c["dt"], "centralized", max_iterations=c["max_iterations"], tolerance=c["tolerance"])
+        dense_cost = np.array([float.fromhex(v) for v in c["cost"]])
+        dense_total = float.fromhex(c["total_cost"])
+        assert abs(e["total_cost"] - dense_total) <= 5e-3 * dense_total, name
+        assert (np.abs(e["cost"] - dense_cost) <= 1e-2 * dense_cost).all(), name
+        assert e["iters"].tolist() == c["iters"], name
+    assert seen == 3
+
+
+def test_exit_codes_and_the_time_limit(gpu_lib, oracle):
+    """ilqr.hpp:82-90,269-271: a solve ends on convergence, on max_iterations, or when elapsed_ms > max_ms at the top
+    of an iteration.  max_ms = -1 is the one deterministic use of the clock (0 > -1: no iteration runs at all)."""
+    from multi_agent_solver_amd.batch import EXIT_CONVERGED, EXIT_MAX_ITER, EXIT_TIME
+    N, T, dt = 70, 40, 0.5
+    x0 = oracle.single_track_x0(N)
+    init = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, "single", max_iterations=0)
+    assert (init["iters"] == 0).all() and (init["status"] == EXIT_MAX_ITER).all()          # the loop body never runs
+    for strategy, outer in (("single", 1), ("sequential", 3), ("trustregion", 2)):
+        for mi, ms, code in ((100, math.inf, EXIT_CONVERGED), (2, math.inf, EXIT_MAX_ITER), (100, -1.0, EXIT_TIME)):
+            e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy, max_outer=outer, max_iterations=mi, max_ms=ms)
+            o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy=strategy, max_outer=outer, max_iterations=mi, max_ms=ms)
+            _same(e, o)
+            if strategy == "single" or ms < 0:          # (for the multi-solve strategies _same compares the last solve's exit with the oracle's)
+                assert (e["status"] == code).all(), (strategy, mi, ms, e["status"])
+            if ms < 0:      # nothing ran: the initial rollout is the answer
+                assert np.array_equal(e["X"], init["X"]) and np.array_equal(e["cost"], init["cost"]) and (e["iters"] == 0).all()
+    # a generous finite budget changes nothing (per-solve clocks on the device, chained solves stay chained)
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, "sequential", max_outer=3, max_ms=1e7)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy="sequential", max_outer=3)
+    _same(e, o)
+    # and a tiny one stops every agent early with EXIT_TIME or before (never more iterations than the unlimited run)
+    t = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(2048), None, 100, dt, "single", max_ms=0.0)
+    assert ((t["status"] & 3) == EXIT_TIME).sum() > 0 and (t["iters"] >= 1).all() and np.isfinite(t["cost"]).all()
+
+
+def test_full_size_config3_properties_and_full_parity(gpu_lib, oracle):
     """BASELINE config 3: 4096 single-track agents, H=100, sequential, max_outer 10.
-    Size-independent properties on ALL agents + exact oracle parity on a sample (agents are
-    independent, so any subset can be re-solved alone by the oracle)."""
+    Size-independent properties + exact oracle parity on ALL 4096 agents (the oracle solves them in seconds)."""
     from multi_agent_solver_amd.batch import BatchSolver
     N, T, dt = 4096, 100, 0.5
     x0 = oracle.single_track_x0(N)
@@ -164,11 +217,13 @@ def test_full_size_config3_properties_and_sampled_parity(gpu_lib, oracle):
     assert np.array_equal(e["X"][:, 0, :], x0)
     assert st["agent_iterations"] == int(e["iters"].sum())
     assert (e["iters"] >= 10).all() and (e["iters"] <= 1000).all()
-    sample = [0, 1, 17, 1023, 2048, 4095]
-    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0[sample], None, T, dt, strategy="sequential")
-    assert np.array_equal(e["cost"][sample], o["cost"])
-    assert np.array_equal(e["X"][sample], o["X"]) and np.array_equal(e["U"][sample], o["U"])
-    assert e["iters"][sample].tolist() == o["iters"].tolist()
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy="sequential")
+    assert np.array_equal(e["cost"], o["cost"])
+    assert np.array_equal(e["X"], o["X"]) and np.array_equal(e["U"], o["U"])
+    assert e["iters"].tolist() == o["iters"].tolist()
+    assert e["status"].tolist() == o["status"].tolist()
+    assert st["reg_events"] == o["stats"]["reg_events"] and st["converged_solves"] == o["stats"]["converged_solves"]
+    assert e["total_cost"] == o["total_cost"]
 
 
 def test_config2_centralized_256(gpu_lib, oracle):
@@ -184,9 +239,9 @@ def test_config4_lqr_shard(gpu_lib, oracle):
     """BASELINE config 4 per-GPU shard: 4096 identity-LQR agents, H=50 (identical agents => identical results)."""
     N, T, dt = 4096, 50, 0.1
     e = run_batch(gpu_lib, oracle.MODEL_LQR_IDENTITY, oracle.lqr_x0(N), None, T, dt, "sequential")
-    o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, oracle.lqr_x0(1), None, T, dt, strategy="sequential")
-    assert (e["cost"] == o["cost"][0]).all() and (e["iters"] == o["iters"][0]).all()
-    assert (e["X"] == o["X"][0]).all()
+    o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, oracle.lqr_x0(N), None, T, dt, strategy="sequential")
+    _same(e, o)
+    assert (e["cost"] == e["cost"][0]).all() and (e["X"] == e["X"][0]).all()      # identical agents => identical results
 
 
 def test_device_pointer_interface_with_torch(gpu_lib, oracle):
@@ -223,9 +278,10 @@ def test_constrained_single_track_augmented_lagrangian(gpu_lib, oracle, strategy
     _same(e, o)
 
 
-def test_config5_bicycle6_shard_properties_and_sampled_parity(gpu_lib, oracle):
+def test_config5_bicycle6_shard_properties_and_full_parity(gpu_lib, oracle):
     """BASELINE config 5 per-GPU shard: 8192 bicycle6 agents (this repository's own nx=6 model), H=200,
-    trust-region strategy, max_outer 10.  Properties on all agents + exact oracle parity on a sample."""
+    trust-region strategy, max_outer 10.  Properties + exact oracle parity on ALL 8192 agents (about a minute of
+    oracle time on the GPU box's host cores)."""
     from multi_agent_solver_amd.batch import BatchSolver, bicycle6_x0
     N, T, dt = 8192, 200, 0.25
     x0 = bicycle6_x0(N)
@@ -241,7 +297,7 @@ def test_config5_bicycle6_shard_properties_and_sampled_parity(gpu_lib, oracle):
     assert np.isfinite(e["cost"]).all() and (e["cost"] <= init["cost"]).all()      # accept only if the cost decreases (nash.hpp:228)
     assert (np.abs(e["U"]) <= 0.5).all()
     assert ((radii > 0) & np.isfinite(radii)).all()
-    sample = [0, 5, 4097, 8191]
-    o = oracle.solve_batch(oracle.MODEL_BICYCLE6, x0[sample], None, T, dt, strategy="trustregion")
-    assert np.array_equal(e["cost"][sample], o["cost"]) and np.array_equal(e["X"][sample], o["X"])
-    assert e["iters"][sample].tolist() == o["iters"].tolist()
+    o = oracle.solve_batch(oracle.MODEL_BICYCLE6, x0, None, T, dt, strategy="trustregion")
+    assert np.array_equal(e["cost"], o["cost"]) and np.array_equal(e["X"], o["X"]) and np.array_equal(e["U"], o["U"])
+    assert e["iters"].tolist() == o["iters"].tolist()
+    assert e["status"].tolist() == o["status"].tolist()

@@ -153,3 +153,47 @@ def test_centralized_ignores_function_constraints_like_the_stacked_ocp(hostcheck
     e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, 20, 0.5, "centralized")
     u = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 20, 0.5, "centralized")
     assert np.array_equal(e["cost"], u["cost"]) and np.array_equal(e["X"], u["X"])
+
+
+def test_exit_codes_and_the_time_limit(hostcheck_lib, oracle):
+    """ilqr.hpp:82-90,269-271 through the host loop: converged / max_iterations / elapsed_ms > max_ms.  max_ms = -1 is
+    the deterministic use of the clock (0 > -1 at the first check: no iteration runs); a generous finite budget must
+    change nothing, including the chained solves of the sequential strategy (per-solve start stamps)."""
+    from multi_agent_solver_amd.batch import EXIT_CONVERGED, EXIT_MAX_ITER, EXIT_TIME
+    N, T, dt = 5, 30, 0.5
+    x0 = oracle.single_track_x0(N)
+    init = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, "single", max_iterations=0)
+    assert (init["iters"] == 0).all() and (init["status"] == EXIT_MAX_ITER).all()
+    for strategy, outer in (("single", 1), ("sequential", 3), ("trustregion", 2), ("linesearch", 2)):
+        for mi, ms, code in ((100, math.inf, EXIT_CONVERGED), (2, math.inf, EXIT_MAX_ITER), (100, -1.0, EXIT_TIME), (100, 1e7, EXIT_CONVERGED)):
+            e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy, max_outer=outer, max_iterations=mi, max_ms=ms)
+            o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy=strategy, max_outer=outer, max_iterations=mi, max_ms=ms)
+            _same(e, o)
+            assert (e["status"] & 3).tolist() == o["status"].tolist(), (strategy, mi, ms)      # last solve of every agent
+            if strategy == "single" or ms < 0:
+                assert (e["status"] == code).all(), (strategy, mi, ms, e["status"])
+            if ms < 0:
+                assert np.array_equal(e["X"], init["X"]) and np.array_equal(e["cost"], init["cost"]) and (e["iters"] == 0).all()
+
+
+def test_debug_key_prints_the_reference_trace(hostcheck_lib, oracle, capfd):
+    """`debug` (ilqr.hpp:45,79-80,262-267): one "initial" line per solve and one line per iteration of every agent, with
+    the reference's wording; values at stream precision (6 significant digits)."""
+    from multi_agent_solver_amd.batch import BatchSolver
+    x0 = oracle.single_track_x0(2)
+    with BatchSolver(oracle.MODEL_SINGLE_TRACK, 2, 20, 0.5, lib=hostcheck_lib) as s:
+        s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf, "debug": 1.0})
+        s.set_initial_states(x0); s.set_controls(None); s.initialize_problem()
+        s.solve()
+        e = s.solution()
+    out = capfd.readouterr().out.splitlines()
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 20, 0.5, strategy="single")
+    assert np.array_equal(e["cost"], o["cost"])
+    for a in range(2):
+        mine = [ln for ln in out if ln.startswith(f"[agent {a}] ")]
+        assert mine[0].startswith(f"[agent {a}] iLQR initial cost=") and " merit=" in mine[0]
+        its = [ln for ln in mine if " iLQR iter " in ln]
+        assert len(its) == int(o["iters"][a])
+        assert [int(ln.split("iLQR iter ")[1].split(":")[0]) for ln in its] == list(range(len(its)))
+        last = its[-1]
+        assert f"cost={o['cost'][a]:.6g}" in last and "d_merit=" in last and last.endswith("eq_violation=0 ineq_violation=0")
