@@ -6,17 +6,28 @@ A "step" is one complete strategy run (the span the reference times around mas::
 examples/multi_agent_single_track.cpp:123-126) over one batch of synthetic agents whose inputs are
 already resident in HBM:  restore initial (x0, U0=0) -> strategy -> results stay on the device.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2] [--agents-per-gpu A]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--agents-per-gpu A]
+
+Workloads (BASELINE.json `configs`; per-GPU shard sizes, weak scaling over ranks):
+  c3  configs[2]  single-track, sequential (Nash), 4096 agents per GPU, H=100           <- default, the headline
+  c2  configs[1]  single-track, centralized, 256 agents, H=100 (one GPU; measured as `also_config2` in the c3 run)
+  c4  configs[3]  identity LQR, sequential, 4096 agents per GPU (32768 on 8), H=50, + RCCL all-gather of the Solution
+  c5  configs[4]  bicycle6 (nx=6), trust-region, 8192 agents per GPU (65536 on 8), H=200
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
-one rank per GPU, agents sharded by id range (weak scaling: A agents per GPU), no data-path
-collective (agents are decoupled); RCCL is used only to take the MAX of
-the ranks' times and the SUM of their iteration counts.
+one rank per GPU, agents sharded by id range, no data-path collective (agents are
+decoupled); RCCL is used only to take the MAX of the ranks' times and the SUM of their iteration counts -- and, for
+c4, for the publish step of the Nash strategies (nash.hpp:66-71) timed separately as `solution_all_gather`.
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline     -- the linearisation sweep (the kernel north_star names), HIP-event timed in this run
-  cpu_baseline -- the CPU restatement of the reference algorithm (oracle, OpenMP over agents as
-                  nash.hpp:59), timed on this host on a bounded sample of the same workload
+  roofline     -- the linearisation sweep (the kernel north_star names): algorithmic bytes over the
+                  kernel's launch durations measured in this run with HIP events bound to each dispatch
+  utilisation  -- backward / forward pass: issue %, wait %, LDS bank-conflict % (SQ counters cannot be read in-process:
+                  taken from the committed rocprofv3 --pmc passes under profiles/, source stated)
+  parity       -- the timed workload's result against the CPU oracle: exact vs its pure-IEEE-trig mode (the parity
+                  definition) and the measured deviation vs its glibc-trig mode
+  cpu_baseline -- the CPU restatement of the reference algorithm (oracle, OpenMP over agents as nash.hpp:59),
+                  timed on this host on a bounded sample of the same workload
   kernels      -- per-kernel time shares of the timed region
   also_config2 -- the same measurement for BASELINE configs[1] (256 agents, centralized), N=1 only
 """
@@ -33,27 +44,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r2"    # profiles/<round>_pmc_traffic_<workload>.json, profiles/<round>_sq_counters_<workload>.json
 
 
 from multi_agent_solver_amd.dist import shard_range  # noqa: E402  contiguous ranges of the id-sorted block list, one per rank
 
+M_SINGLE_TRACK, M_LQR, M_BICYCLE6 = 1, 2, 5
 
 WORKLOADS = {
-    # BASELINE.json configs[2]
     "c3": dict(name="multi_agent_single_track --solver ilqr --strategy sequential, 4096 agents per GPU, H=100 (BASELINE configs[2])",
-               agents=4096, T=100, dt=0.5, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5),
-    # BASELINE.json configs[1]
+               model=M_SINGLE_TRACK, nx=4, nu=2, agents=4096, T=100, dt=0.5, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5,
+               sweep_bytes_per_agent=51392),
     "c2": dict(name="multi_agent_single_track --solver ilqr --strategy centralized, 256 agents, H=100 (BASELINE configs[1])",
-               agents=256, T=100, dt=0.5, strategy="centralized", max_outer=1, max_iterations=100, tolerance=1e-5),
+               model=M_SINGLE_TRACK, nx=4, nu=2, agents=256, T=100, dt=0.5, strategy="centralized", max_outer=1, max_iterations=100, tolerance=1e-5,
+               sweep_bytes_per_agent=51392),
+    "c4": dict(name="multi_agent_lqr --solver ilqr --strategy sequential, 4096 agents per GPU (32768 on 8), H=50 (BASELINE configs[3])",
+               model=M_LQR, nx=4, nu=4, agents=4096, T=50, dt=0.1, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5,
+               sweep_bytes_per_agent=38592),
+    "c5": dict(name="multi_agent_single_track --solver ilqr --strategy trustregion, nx=6 bicycle model, 8192 agents per GPU (65536 on 8), H=200 (BASELINE configs[4])",
+               model=M_BICYCLE6, nx=6, nu=2, agents=8192, T=200, dt=0.25, strategy="trustregion", max_outer=10, max_iterations=100, tolerance=1e-5,
+               sweep_bytes_per_agent=185984),
 }
 
 
+def initial_states(w, n_local, first, n_total):
+    """the reference's closed-form generators; rows are agents first .. first+n_local-1"""
+    from multi_agent_solver_amd.batch import single_track_x0, lqr_x0, bicycle6_x0
+    if w["model"] == M_SINGLE_TRACK:
+        return single_track_x0(n_local, first=first, total=n_total)
+    if w["model"] == M_LQR:
+        return lqr_x0(n_local)
+    return bicycle6_x0(n_local, first=first, total=n_total)
+
+
 def make_solver(w, n_local, first, n_total, device):
-    from multi_agent_solver_amd import BatchSolver, MODEL_SINGLE_TRACK
-    from multi_agent_solver_amd.batch import single_track_x0
-    s = BatchSolver(MODEL_SINGLE_TRACK, n_local, w["T"], w["dt"], device=device)
+    from multi_agent_solver_amd import BatchSolver
+    s = BatchSolver(w["model"], n_local, w["T"], w["dt"], device=device)
     s.set_params({"max_iterations": w["max_iterations"], "tolerance": w["tolerance"], "max_ms": math.inf})
-    s.set_initial_states(single_track_x0(n_local, first=first, total=n_total))
+    s.set_initial_states(initial_states(w, n_local, first, n_total))
     s.set_controls(None)
     s.initialize_problem()
     s.save_initial()
@@ -97,61 +125,136 @@ def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier, af
     return elapsed, st, kt, sol
 
 
-def cpu_baseline(w, n_total, budget_agents=None):
+def oracle_run(w, x0, trig, threads=0):
+    from oracle import oracle as O
+    O.set_trig_mode(trig)
+    try:
+        return O.solve_batch(w["model"], x0, None, w["T"], w["dt"], strategy=w["strategy"], max_outer=w["max_outer"],
+                             max_iterations=w["max_iterations"], tolerance=w["tolerance"], threads=threads)
+    finally:
+        O.set_trig_mode("libm")
+
+
+def cpu_baseline(w, n_total):
     """CPU restatement of the reference algorithm (oracle/), OpenMP over agents like nash.hpp:59.
     Bounded sample: every k-th agent of the workload, whole strategy."""
     from oracle import oracle as O
-    import numpy as np
-    from multi_agent_solver_amd.batch import single_track_x0
     threads = O.max_threads()
-    O.set_trig_mode("libm")      # std::sin/cos/tan, as the reference binary calls them
-    n = budget_agents or min(n_total, 64 * threads)
+    n = min(n_total, 64 * threads)
     stride = max(1, n_total // n)
-    x0 = single_track_x0(n_total)[::stride][:n]
-    its, el, reps, r = 0, 0.0, 0, None
+    x0 = initial_states(w, n_total, 0, n_total)[::stride][:n]
+    its, el, reps = 0, 0.0, 0
     while el < 8.0 and reps < 20:            # bounded: about 10 s of CPU work
         t0 = time.perf_counter()
-        r = O.solve_batch(O.MODEL_SINGLE_TRACK, x0, None, w["T"], w["dt"], strategy=w["strategy"], max_outer=w["max_outer"],
-                          max_iterations=w["max_iterations"], tolerance=w["tolerance"], threads=threads)
+        r = oracle_run(w, x0, "libm", threads)      # std::sin/cos/tan, as the reference binary calls them
         el += time.perf_counter() - t0
         its += int(r["stats"]["total_iterations"]) * (x0.shape[0] if w["strategy"] == "centralized" else 1)
         reps += 1
     return dict(value=its / el, unit="agent-iterations/s", cores=threads, kind="port",
                 sample=f"{x0.shape[0]} agents (every {stride}th of {n_total}), full '{w['strategy']}' strategy run repeated {reps}x, {el:.1f} s total; "
-                       f"CPU restatement of reference algorithm (oracle/, gcc -O2 -ffp-contract=off, OpenMP schedule(static) over agents as nash.hpp:59, glibc trig)"), r, x0
+                       f"CPU restatement of reference algorithm (oracle/, gcc -O2 -ffp-contract=off, OpenMP schedule(static) over agents as nash.hpp:59, glibc trig)")
 
 
-def roofline_of(kt, name="sweep"):
-    # prefer the in-kernel REFCLK timing of the sweep (kernel execution span, what rocprofv3 --kernel-trace
-    # reports); the host-side event timing of the same launches carries ~5 us of dispatch overhead each
-    k = kt.get(name + "_inkernel") or kt.get(name)
+def parity_block(w, sol, n_total, max_agents=4096):
+    """The timed workload's final result against the CPU oracle, outside the timed region.
+    vs_det_oracle : the oracle with the shared pure-IEEE sin/cos/tan (include/mas_dettrig.h) -- the parity definition of
+                    this repository: "exact" means costs, trajectories, controls and iteration
+                    counts are bit-identical for every compared agent.
+    vs_libm_oracle: the same oracle with glibc's sin/cos/tan, i.e. what a glibc-linked reference binary computes.
+                    north_star asks for <= 1e-5 relative cost error; the algorithm amplifies last-bit differences of the
+                    trig functions chaotically (tests/test_oracle_sensitivity.py), so this is reported as measured."""
+    import numpy as np
+    x0_all = initial_states(w, n_total, 0, n_total)
+    stride = max(1, -(-n_total // max_agents))
+    idx = np.arange(0, n_total, stride)
+    if w["strategy"] == "centralized":
+        idx = np.arange(n_total)                      # agents share alpha / termination / ladder: the whole problem or nothing
+    x0 = x0_all[idx]
+    t0 = time.perf_counter()
+    det = oracle_run(w, x0, "det")
+    exact = (np.array_equal(sol["cost"][idx], det["cost"]) and np.array_equal(sol["X"][idx], det["X"]) and
+             np.array_equal(sol["U"][idx], det["U"]) and sol["iters"][idx].tolist() == det["iters"].tolist())
+    rel_det = np.abs(sol["cost"][idx] - det["cost"]) / np.abs(det["cost"])
+    lib = oracle_run(w, x0, "libm")
+    rel = np.abs(sol["cost"][idx] - lib["cost"]) / np.abs(lib["cost"])
+    out = {
+        "compared_agents": int(idx.size), "of": int(n_total), "sample": ("all agents" if stride == 1 or w["strategy"] == "centralized" else f"every {stride}th agent (agents are independent: a subset is re-solved alone by the oracle)"),
+        "definition": "bit-exact against the CPU oracle in its pure-IEEE-trig mode (DESIGN.md section 2.1); the glibc-trig deviation is what north_star's <=1e-5 asks about",
+        "vs_det_oracle": "exact" if exact else {"max_rel_cost": float(rel_det.max()), "iters_equal_frac": float(np.mean(sol["iters"][idx] == det["iters"]))},
+        "vs_libm_oracle": {"median_rel": float(np.median(rel)), "max_rel": float(rel.max()),
+                           "total_rel": float(abs(sol["cost"][idx].sum() - lib["cost"].sum()) / abs(lib["cost"].sum())),
+                           "frac_le_1e-5": float(np.mean(rel <= 1e-5)), "iters_equal_frac": float(np.mean(sol["iters"][idx] == lib["iters"])),
+                           "north_star_tolerance_1e-5_met": bool(rel.max() <= 1e-5)},
+        "oracle_seconds": round(time.perf_counter() - t0, 2),
+    }
+    if w["strategy"] == "centralized":
+        out["vs_reference_stacked_solve"] = ("NOT the same number: the reference finite-differences the summed cost of the stacked problem "
+                                             "(centralized.hpp:18-38, multi_agent_problem.hpp:94-122), whose Hessians carry FD noise in the cross-agent blocks; "
+                                             "this path solves the block-diagonal reading.  Literal stacked solve is 4*(4N)^2 global cost evaluations per step "
+                                             "(not computable at 256 agents); at N = 2/4/10, T = 10 the totals differ by 2.6e-4 / 3.2e-5 / 1.3e-3 "
+                                             "(tests/test_gpu_parity.py::test_centralized_against_the_dense_stacked_goldens)")
+    return out
+
+
+def _load_profile(kind, workload):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{kind}_{workload}.json")
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except (OSError, ValueError):
+        return None, None
+
+
+def roofline_of(kt, w, workload, name="sweep"):
+    """achieved = algorithmic bytes (SURVEY.md 8(d) per agent x active agents of each launch) / launch durations.
+    `frac` uses the HIP events bound to each dispatch of the instrumented pass (every launch of the kernel, including
+    the empty run-ahead launch at the end of each solve) -- the quantity rocprofv3 --kernel-trace averages, so
+    profiles/*_kernel_stats.csv can be held against it.  `inkernel_span` is the same sum over the kernel's own
+    first-workgroup-start .. last-workgroup-end REFCLK stamps (no dispatch ramp)."""
+    k = kt.get(name)
     if not k or k["launches"] == 0 or k["total_ms"] <= 0:
         return None
     achieved = k["algorithmic_bytes"] / (k["total_ms"] * 1e-3) / 1e9
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the ratio measured/algorithmic
-    # of the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic_*.json, corrected as MI355X_MICROARCH.md
-    # prescribes) is applied to this run's algorithmic bytes per launch.  None when no such profile is present.
-    traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3.json")))
-        if name == "sweep":
-            ratio = (pmc["sweep"]["fetch_bytes_corrected_KB"] + pmc["after_chunk_major_tile_layout"]["sweep_WRITE_SIZE_KB_first_dispatch"]) / \
-                    (pmc["sweep"]["algorithmic_read_KB"] + pmc["sweep"]["algorithmic_write_KB"])
-            traffic = ratio * k["algorithmic_bytes"] / k["launches"]
-            traffic_src = f"profiles/r1_pmc_traffic_c3.json (FETCH_SIZE x2 + WRITE_SIZE = {ratio:.4f} x algorithmic bytes on a full launch)"
-    except (OSError, KeyError, ValueError):
-        pass
+    out = dict(bound="hbm", kernel="mas_sweep_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+               timing="HIP events bound to each dispatch (hipExtLaunchKernelGGL), all launches of the instrumented pass",
+               launches=k["launches"], avg_launch_us=1e3 * k["total_ms"] / k["launches"],
+               algorithmic_bytes_per_launch=k["algorithmic_bytes"] / k["launches"],
+               algorithmic_bytes_per_agent=w["sweep_bytes_per_agent"],
+               algorithmic_bytes_note="SURVEY.md 8(d): read 8[(nx+nu)T+nx] + write 8[T*ND+nx+nx^2]; the kernel itself moves 8(2nx+nx^2) B less per agent (x_T, terminal v_x/v_xx belong to the backward kernel)")
+    ik = kt.get(name + "_inkernel")
+    if ik and ik["launches"] and ik["total_ms"] > 0:
+        a = ik["algorithmic_bytes"] / (ik["total_ms"] * 1e-3) / 1e9
+        out["inkernel_span"] = dict(achieved=a, frac=a / HBM_PEAK_GBS, launches=ik["launches"], avg_launch_us=1e3 * ik["total_ms"] / ik["launches"])
     full = kt.get(name + "_inkernel_full")
-    full_info = None
     if full and full["launches"] and full["total_ms"] > 0:
         fa = full["algorithmic_bytes"] / (full["total_ms"] * 1e-3) / 1e9
-        full_info = dict(launches=full["launches"], avg_launch_us=1e3 * full["total_ms"] / full["launches"], achieved=fa, frac=fa / HBM_PEAK_GBS,
-                         note="launches in which every agent of the batch is still active (first round of each solve)")
-    return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                all_agents_active=full_info,
-                traffic=traffic, traffic_source=traffic_src, timing=("in-kernel s_memrealtime span" if (name + "_inkernel") in kt else "hip events"),
-                launches=k["launches"], avg_launch_us=1e3 * k["total_ms"] / k["launches"],
-                algorithmic_bytes_per_launch=k["algorithmic_bytes"] / k["launches"])
+        out["all_agents_active"] = dict(launches=full["launches"], avg_launch_us=1e3 * full["total_ms"] / full["launches"], achieved=fa, frac=fa / HBM_PEAK_GBS,
+                                        timing="in-kernel span", note="launches in which every agent of the batch is still active (first round of each solve): the kernel at its design point")
+    # HBM traffic: PMC counters cannot be read from inside this process.  DERIVED figure: the measured/algorithmic ratio of
+    # the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, corrected as MI355X_MICROARCH.md
+    # prescribes: FETCH_SIZE x2 on gfx950) applied to this run's algorithmic bytes per launch.  None without the profile.
+    pmc, src = _load_profile("pmc_traffic", workload)
+    out["traffic"], out["traffic_source"] = None, None
+    if pmc and "sweep" in pmc.get("kernels", {}):
+        ratio = pmc["kernels"]["sweep"].get("measured_over_algorithmic")
+        if ratio:
+            out["traffic"] = ratio * out["algorithmic_bytes_per_launch"]
+            out["traffic_source"] = f"derived: {src} (FETCH_SIZE x2 + WRITE_SIZE = {ratio:.4f} x algorithmic bytes over the launches of one strategy run; collected at {pmc.get('commit', 'unknown commit')})"
+    return out
+
+
+def utilisation_of(workload):
+    """backward / forward pass against the SIMD they run on: SQ counters of the committed rocprofv3 --pmc passes
+    (north_star: 'LDS/MFMA utilisation on the backward pass'; no MFMA is used -- fused multiply-adds would break the
+    reference's SSE2 rounding)."""
+    sq, src = _load_profile("sq_counters", workload)
+    if not sq:
+        return None
+    out = {"source": f"{src} (rocprofv3 --pmc, SQ counters of one strategy run; collected at {sq.get('commit', 'unknown commit')})"}
+    for name in ("backward", "forward", "sweep"):
+        k = sq.get("kernels", {}).get(name)
+        if k and "derived" in k:
+            out[name] = k["derived"]
+    return out
 
 
 def main():
@@ -162,12 +265,13 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--agents-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for a single rank (exercises the RCCL path on one GPU)")
     ap.add_argument("--gather-solution", action="store_true",
                     help="after the timed region, also time the all-gather of the whole Solution over RCCL (the publish step of coupled "
-                         "Nash problems, nash.hpp:66-71); reported as 'solution_all_gather', never part of 'value'")
+                         "Nash problems, nash.hpp:66-71); reported as 'solution_all_gather', never part of 'value'.  On by default for c4 with N > 1.")
     args = ap.parse_args()
 
     import torch
@@ -203,7 +307,7 @@ def main():
     lo, hi = shard_range(n_total, world, rank)
 
     gather = None
-    if args.gather_solution and dist is not None:
+    if (args.gather_solution or (args.workload == "c4" and world > 1)) and dist is not None:
         def gather(solver):
             from multi_agent_solver_amd.dist import all_gather_solution
             times = []
@@ -212,8 +316,10 @@ def main():
                 full = all_gather_solution(solver, n_total)
                 sync(); barrier(); times.append(time.perf_counter() - t0)
             nbytes = sum(v.numel() * 8 for v in full.values())
-            return {"ms": 1e3 * min(times), "bytes_received_per_rank": nbytes, "GBs_per_rank": nbytes / min(times) / 1e9, "collective": "all_gather x3 (X, U, cost)"}
-    elapsed, st, kt, _ = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier, after=gather)
+            return {"ms": 1e3 * min(times), "bytes_received_per_rank": nbytes, "GBs_per_rank": nbytes / min(times) / 1e9, "collective": "all_gather x3 (X, U, cost)",
+                    "what": "publish step of the Nash strategies (update_initial_with_best, nash.hpp:66-71): every rank receives every agent's trajectory; "
+                            "off the timed path because decoupled agents (every shipped example) do not consume it"}
+    elapsed, st, kt, sol = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier, after=gather)
     vals = torch.tensor([elapsed, float(st["agent_iterations"]), float(st["converged_solves"]), float(st["solves"])],
                         dtype=torch.float64, device=("cuda" if args.backend == "nccl" else "cpu"))
     if dist is not None:
@@ -233,29 +339,29 @@ def main():
             "metric": "ilqr_agent_iterations_per_sec", "value": iters / elapsed, "unit": "agent-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": w["name"], "agents_per_gpu": per_gpu, "agents_total": n_total, "horizon": w["T"], "nx": 4, "nu": 2,
+            "config": {"workload": w["name"], "agents_per_gpu": per_gpu, "agents_total": n_total, "horizon": w["T"], "nx": w["nx"], "nu": w["nu"],
                        "strategy": w["strategy"], "max_outer": w["max_outer"], "max_iterations": w["max_iterations"],
                        "tolerance": w["tolerance"], "sharding": f"agents by id range over {world} rank(s), no data-path collective"},
             "converged_agent_trajectories_per_sec": (n_total * args.steps) / elapsed if w["strategy"] != "centralized" else None,
             "agent_iterations_per_step": iters / args.steps,
             "converged_solves_fraction": conv / max(1.0, solves),
-            "roofline": roofline_of(kt, "sweep"),
+            "roofline": roofline_of(kt, w, args.workload, "sweep"),
+            "utilisation": utilisation_of(args.workload),
             "kernels": kernels,
             "kernel_time_fraction_of_wall": total_kernel_ms * 1e-3 / st["profiled_pass_elapsed"],
             "instrumented_pass_ms_per_step": 1e3 * st["profiled_pass_elapsed"] / args.steps,
         }
         if st.get("after") is not None:
             out["solution_all_gather"] = st["after"]
-        if world == 1 and not args.no_cpu_baseline:
-            cb, _, _ = cpu_baseline(w, n_total)
-            out["cpu_baseline"] = cb
-        else:
-            out["cpu_baseline"] = None
+        out["parity"] = parity_block(w, sol, n_total) if (world == 1 and not args.no_parity) else None
+        out["cpu_baseline"] = cpu_baseline(w, n_total) if (world == 1 and not args.no_cpu_baseline) else None
         if world == 1 and not args.no_also and args.workload == "c3":
             w2 = dict(WORKLOADS["c2"])
-            el2, st2, kt2, _ = measure(w2, w2["agents"], 0, w2["agents"], device, max(3, args.steps), 1, sync, barrier)
+            el2, st2, kt2, sol2 = measure(w2, w2["agents"], 0, w2["agents"], device, max(3, args.steps), 1, sync, barrier)
             out["also_config2"] = {"workload": w2["name"], "value": st2["agent_iterations"] / el2, "unit": "agent-iterations/s",
-                                   "ms_per_step": 1e3 * el2 / max(3, args.steps), "roofline": roofline_of(kt2, "sweep")}
+                                   "ms_per_step": 1e3 * el2 / max(3, args.steps), "roofline": roofline_of(kt2, w2, "c2", "sweep"),
+                                   "kernels_avg_us": {n: round(1e3 * k["total_ms"] / max(1, k["launches"]), 2) for n, k in kt2.items() if "_inkernel" not in n},
+                                   "parity": None if args.no_parity else parity_block(w2, sol2, w2["agents"])}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

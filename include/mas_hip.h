@@ -20,6 +20,33 @@
  *    device pointers in the same layout (used with torch tensors' data_ptr());
  *  - a handle is bound to one HIP device and one stream and is not thread-safe
  *    (one handle per GPU, as one rank per GPU under torch.distributed).
+ *
+ * Stream ordering of the `*_device` entry points
+ *    A handle made by mas_hip_create works on its OWN non-blocking stream; one made by mas_hip_create_on_stream works on
+ *    the caller's stream.  With its own stream nothing orders the handle's copies against work the caller has queued on
+ *    other streams, so the contract is: (1) the contents of an input buffer (set_*_device) and any pending writes to an
+ *    output buffer (get_solution_device; e.g. an allocator's zero-fill) must be COMPLETE before the call -- synchronise the
+ *    producing stream, or share one stream through mas_hip_create_on_stream; (2) every `*_device` call synchronises the
+ *    handle's stream before it returns: inputs are no longer referenced, outputs are complete.
+ *
+ * Device exclusivity of the centralised strategy
+ *    mas_hip_run_centralized agrees on one regularisation rung per time step across all its workgroups with a spin barrier
+ *    in global memory, which needs all of them (N/4 single-wavefront workgroups, N <= 1024) resident on the device at the
+ *    same time.  The library checks that they fit this device (occupancy query) and otherwise uses a slower single-workgroup
+ *    kernel, but it cannot see OTHER work: do not run kernels from other streams or processes on the device while a
+ *    centralised solve is in flight.  If the barrier starves, the call fails with MAS_HIP_ERR_RUNTIME ("gave up waiting for
+ *    the rung agreement") instead of hanging.
+ *
+ * Two documented departures from a glibc-linked reference binary
+ *  - sin/cos/tan come from include/mas_dettrig.h (pure IEEE + - * /, <= 1 ulp from glibc for sin/cos, <= 3 ulp for tan) so
+ *    that GPU and CPU oracle agree bit for bit.  Its argument range is |x| <= 1.6e6 (three-term Cody-Waite reduction);
+ *    beyond it the functions return NaN where glibc returns a value.  A line-search trial that reaches such a heading or
+ *    steering angle gets a NaN merit and is rejected (NaN < best is false), and a non-finite accepted cost is flagged with
+ *    MAS_HIP_EXIT_NONFINITE.  None of the shipped workloads comes within five orders of magnitude of the limit.
+ *  - max_ms (ilqr.hpp:84-90) is honoured per solve with a clock started on the device when the agent's solve begins; the
+ *    check for iteration i+1 is made at the end of iteration i (a few microseconds before the reference's check at the top
+ *    of the loop).  All agents of a batch run concurrently, so a budget buys each agent about as many iterations as the
+ *    batch completes rounds in that time -- fewer than N serial CPU solves would get when N is large.
  */
 #ifndef MAS_HIP_H
 #define MAS_HIP_H
@@ -90,7 +117,7 @@ const char* mas_hip_last_error(const mas_hip_solver*);   /* NULL handle: last cr
 
 /* ---- solver parameters: iLQR::set_params, ilqr.hpp:39-55 ----
  * keys "max_iterations", "tolerance", "max_ms" (required by the reference: params.at()),
- * optional "debug" (one stdout line per batch round instead of one per agent and iteration), "penalty", "penalty_increase", "constraint_tolerance",
+ * optional "debug" (the reference's per-solve and per-iteration lines, ilqr.hpp:79-80,262-267, prefixed "[agent i] "), "penalty", "penalty_increase", "constraint_tolerance",
  * "inequality_activation_tolerance" (augmented-Lagrangian branch, ilqr.hpp:47-54);
  * unknown keys are ignored like the reference. */
 int mas_hip_set_param(mas_hip_solver*, const char* key, double value);

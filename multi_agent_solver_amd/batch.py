@@ -104,8 +104,31 @@ class BatchSolver:
             U = np.ascontiguousarray(U, dtype=np.float64).reshape(self.N, self.T, self.nu)
             self._check(self._lib.mas_hip_set_controls_host(self._h, _dp(U)))
 
+    # Device-pointer entry points -- stream-ordering contract (include/mas_hip.h): the handle runs on its own stream.  The
+    # caller makes the buffer's contents ready before the call (e.g. torch.cuda.current_stream().synchronize(), or create
+    # the BatchSolver with stream=torch.cuda.current_stream().cuda_stream); on return the handle has finished with it.
     def set_initial_states_device(self, ptr: int):
         self._check(self._lib.mas_hip_set_initial_states_device(self._h, C.c_void_p(ptr)))
+
+    def set_initial_states_torch(self, t):
+        """x0 from a torch CUDA tensor [N, nx] (float64, contiguous), ordered after the work queued on torch's current stream"""
+        import torch
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (self.N, self.nx)
+        torch.cuda.current_stream(t.device).synchronize()
+        self.set_initial_states_device(t.data_ptr())
+
+    def set_controls_torch(self, t):
+        import torch
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (self.N, self.T, self.nu)
+        torch.cuda.current_stream(t.device).synchronize()
+        self.set_controls_device(t.data_ptr())
+
+    def solution_torch(self, X=None, U=None, cost=None):
+        """write the Solution into preallocated torch CUDA tensors (any may be None); complete on return"""
+        import torch
+        dev = next(t.device for t in (X, U, cost) if t is not None)
+        torch.cuda.current_stream(dev).synchronize()       # pending torch writes to the buffers (e.g. their zero-fill) come first
+        self.solution_device(X.data_ptr() if X is not None else 0, U.data_ptr() if U is not None else 0, cost.data_ptr() if cost is not None else 0)
 
     def set_controls_device(self, ptr: int):
         self._check(self._lib.mas_hip_set_controls_device(self._h, C.c_void_p(ptr)))

@@ -402,6 +402,7 @@ class SolverImpl final : public SolverBase {
   void launch_central_backward(double bytes) {
 #if !defined(MAS_HOST_EMULATION)
     if constexpr (!kConstrained) {
+      if (ladder_resident()) {
       const size_t words = static_cast<size_t>(d.T) * LadderSync::kChunks * 4;
       if (!ladder_sync) ladder_sync = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * (words + 2)));
       MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
@@ -413,6 +414,7 @@ class SolverImpl final : public SolverBase {
       be.end();
       ladder_error_pending = true;
       return;
+      }
     }
 #endif
     if (!Dsoa) Dsoa = dalloc(static_cast<size_t>(d.T) * L::ND * d.Np);
@@ -435,6 +437,27 @@ class SolverImpl final : public SolverBase {
     be.end();
 #endif
   }
+
+#if !defined(MAS_HOST_EMULATION)
+  // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
+  // them resident at once.  Checked against the occupancy the runtime reports for this kernel on this device (a
+  // partitioned device, e.g. CPX with 32 CUs, or a build with higher register use may not hold them); if they do not fit,
+  // the single-workgroup CentralBackwardBody is used instead -- slower, but it cannot starve.  Work of OTHER streams or
+  // processes on the device is outside what can be checked here: mas_hip.h states the exclusivity requirement.
+  bool ladder_resident() {
+    if (ladder_resident_checked) return ladder_resident_ok;
+    ladder_resident_checked = true;
+    constexpr int apw = 64 / kBackwardLanesPerAgent;
+    const int grid = (d.N + apw - 1) / apw;
+    int per_cu = 0; hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true>, 64, 0) != hipSuccess ||
+        hipGetDeviceProperties(&prop, be.device) != hipSuccess) { (void)hipGetLastError(); ladder_resident_ok = false; return false; }
+    ladder_resident_ok = static_cast<long long>(per_cu) * prop.multiProcessorCount >= grid;
+    if (const char* f = std::getenv("MAS_HIP_FORCE_SINGLE_WORKGROUP_CENTRAL")) { if (f[0] == '1') ladder_resident_ok = false; }   // tests: exercise the fallback
+    return ladder_resident_ok;
+  }
+  bool ladder_resident_checked = false, ladder_resident_ok = false;
+#endif
 
   ALView al_view(bool on) const {
     ALView v;
@@ -595,7 +618,9 @@ class SolverImpl final : public SolverBase {
   }
   void fill(double* dev, double v) { std::vector<double> h(d.Np, v); be.h2d(dev, h.data(), sizeof(double) * d.Np); }
   void fill_int(int* dev, int v) { std::vector<int> h(d.Np, v); be.h2d(dev, h.data(), sizeof(int) * d.Np); }
-  void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); } else be.h2d(stage, src, sizeof(double) * n); }
+  // device pointers: the copy runs on the handle's stream and is complete on return, so the caller's buffer is no longer
+  // referenced afterwards; the caller must have made its contents ready before the call (mas_hip.h, stream-ordering contract)
+  void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); be.sync(); } else be.h2d(stage, src, sizeof(double) * n); }
   void download(double* dst, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(dst, stage, sizeof(double) * n); be.sync(); } else be.d2h(dst, stage, sizeof(double) * n); }
   void* raw_alloc(size_t bytes) { void* p = be.alloc(bytes); allocations.push_back(p); return p; }   // freed by the destructor
   void check_ladder_sync() {

@@ -33,6 +33,28 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert j["also_config2"]["value"] > 0
+    # parity block: exact against the pure-IEEE-trig oracle, measured deviation against the glibc-trig one
+    p = j["parity"]
+    assert p["vs_det_oracle"] == "exact" and p["compared_agents"] == 512
+    assert set(p["vs_libm_oracle"]) >= {"median_rel", "max_rel", "total_rel", "frac_le_1e-5", "north_star_tolerance_1e-5_met"}
+    assert j["also_config2"]["parity"]["vs_det_oracle"] == "exact"
+    assert r_has_both_fracs(j["roofline"])
+
+
+def r_has_both_fracs(r):
+    return "inkernel_span" in r and 0.0 < r["inkernel_span"]["frac"] < 1.0 and r["algorithmic_bytes_per_agent"] == 51392
+
+
+@pytest.mark.parametrize("workload,agents,bytes_per_agent", [("c4", 256, 38592), ("c5", 128, 185984)])
+def test_config4_and_config5_are_bench_workloads(workload, agents, bytes_per_agent):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
+                          "--agents-per-gpu", str(agents)], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    _check_line(j, 1)
+    assert j["roofline"]["algorithmic_bytes_per_agent"] == bytes_per_agent
+    assert j["parity"]["vs_det_oracle"] == "exact"
+    assert j["cpu_baseline"]["value"] > 0
 
 
 def test_rccl_path_initialises_with_one_rank():

@@ -180,8 +180,11 @@ def test_exit_codes_and_the_time_limit(gpu_lib, oracle):
             e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy, max_outer=outer, max_iterations=mi, max_ms=ms)
             o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy=strategy, max_outer=outer, max_iterations=mi, max_ms=ms)
             _same(e, o)
-            if strategy == "single" or ms < 0:          # (for the multi-solve strategies _same compares the last solve's exit with the oracle's)
+            # _same compared every agent's exit with the oracle's; here: the intended exit really occurs
+            if ms < 0 or (strategy == "single" and mi == 100):
                 assert (e["status"] == code).all(), (strategy, mi, ms, e["status"])
+            elif strategy == "single":
+                assert (e["status"] == code).sum() > N // 2 and set(e["status"].tolist()) <= {EXIT_CONVERGED, EXIT_MAX_ITER}
             if ms < 0:      # nothing ran: the initial rollout is the answer
                 assert np.array_equal(e["X"], init["X"]) and np.array_equal(e["cost"], init["cost"]) and (e["iters"] == 0).all()
     # a generous finite budget changes nothing (per-solve clocks on the device, chained solves stay chained)
@@ -267,6 +270,51 @@ def test_device_pointer_interface_with_torch(gpu_lib, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(X_out.cpu().numpy(), host["X"])
     assert np.array_equal(c_out.cpu().numpy(), host["cost"])
+
+
+def test_torch_tensors_without_a_manual_synchronize(gpu_lib, oracle):
+    """the handle works on its own stream.  The *_torch helpers order the handle's copies after torch's
+    current stream (stream-ordering contract in include/mas_hip.h); here the inputs are produced by queued torch
+    kernels and the outputs are freshly zero-filled, with no torch.cuda.synchronize() anywhere in the test."""
+    import torch
+    from multi_agent_solver_amd.batch import BatchSolver
+    N, T = 512, 20
+    x0 = oracle.single_track_x0(N)
+    dev = torch.device("cuda:0")
+    big = torch.ones((4096, 4096), device=dev)
+    for _ in range(10):                                 # keep torch's stream busy while the tensors below are produced
+        big = big @ big * 1e-4
+    x0_t = torch.from_numpy(x0).to(dev) * 1.0
+    U_t = torch.zeros((N, T, 2), dtype=torch.float64, device=dev) + 0.0
+    with BatchSolver(oracle.MODEL_SINGLE_TRACK, N, T, 0.5, lib=gpu_lib) as s:
+        s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+        s.set_initial_states_torch(x0_t)
+        s.set_controls_torch(U_t)
+        s.initialize_problem()
+        s.run_sequential(2)
+        for _ in range(10):
+            big = big @ big * 1e-4
+        X_out = torch.zeros((N, T + 1, 4), dtype=torch.float64, device=dev)
+        U_out = torch.zeros((N, T, 2), dtype=torch.float64, device=dev)
+        c_out = torch.zeros((N,), dtype=torch.float64, device=dev)
+        s.solution_torch(X_out, U_out, c_out)
+        host = s.solution()
+    assert np.array_equal(X_out.cpu().numpy(), host["X"]) and np.array_equal(U_out.cpu().numpy(), host["U"])
+    assert np.array_equal(c_out.cpu().numpy(), host["cost"])
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy="sequential", max_outer=2)
+    assert np.array_equal(host["cost"], o["cost"])
+
+
+def test_centralized_single_workgroup_fallback(gpu_lib, oracle, monkeypatch):
+    """when the workgroups of the rung-agreement kernel cannot all be resident (occupancy check), the
+    centralised backward pass falls back to the single-workgroup kernel -- same results, bit for bit."""
+    x0 = oracle.single_track_x0(70)
+    fast = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 40, 0.5, "centralized")
+    monkeypatch.setenv("MAS_HIP_FORCE_SINGLE_WORKGROUP_CENTRAL", "1")
+    slow = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 40, 0.5, "centralized")
+    for key in ("cost", "X", "U", "iters"):
+        assert np.array_equal(fast[key], slow[key]), key
+    assert fast["stats"]["reg_events"] == slow["stats"]["reg_events"] and fast["total_cost"] == slow["total_cost"]
 
 
 @pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 3), ("trustregion", 3)])

@@ -2,7 +2,7 @@
 If the forward kernel still slows down in the late rounds the cause is the data, not the exec mask."""
 import math, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
 def run(x0, tag):
     N = x0.shape[0]

@@ -1,10 +1,26 @@
-"""One C3 strategy run (4096 single-track agents, sequential, max_outer 10) for counter collection."""
-import math, sys
-sys.path.insert(0, "/root/repo")
-from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-s = BatchSolver(1, N, 100, 0.5)
-s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
-s.set_initial_states(single_track_x0(N)); s.set_controls(None); s.initialize_problem()
-s.run_sequential(10)
-print("iterations", s.stats()["agent_iterations"])
+"""One strategy run of a BASELINE workload shard (bench.py's WORKLOADS) for counter collection under rocprofv3.
+usage: one_run.py [c3|c2|c4|c5] [agents] [--algorithmic out.json]
+--algorithmic: no profiler needed; writes the per-kernel launch counts and algorithmic bytes of the same
+(deterministic) run, which tools/summarise_profiles.py holds the PMC byte counters against."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+wname = args[0] if args else "c3"
+w = dict(bench.WORKLOADS[wname])
+N = int(args[1]) if len(args) > 1 else w["agents"]
+s = bench.make_solver(w, N, 0, N, 0)
+if "--algorithmic" in sys.argv:
+    s.set_profiling(True)
+s.reset_stats()
+bench.one_step(s, w)
+st = s.stats()
+print("workload", wname, "agents", N, "iterations", st["agent_iterations"], "rounds", st["batch_iterations"])
+if "--algorithmic" in sys.argv:
+    out = sys.argv[sys.argv.index("--algorithmic") + 1]
+    json.dump({"workload": wname, "agents": N, "stats": st, "kernels": s.kernel_times()}, open(out, "w"), indent=1)

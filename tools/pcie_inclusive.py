@@ -1,7 +1,7 @@
 """C3 through the HOST-buffer entry points (one PCIe copy each way): rate including the transfers."""
 import math, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
 N, T = 4096, 100
 x0 = single_track_x0(N); U0 = np.zeros((N, T, 2))

@@ -1,7 +1,7 @@
 """Per-kernel timing of one BASELINE config shard on one GPU (HIP events / in-kernel stamps).
 usage: python tools/profile_config.py c2|c3|c4|c5 [agents]"""
 import math, sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_agent_solver_amd.batch import BatchSolver, single_track_x0, lqr_x0, bicycle6_x0
 cfg = sys.argv[1]
 CFG = {"c2": (1, 256, 100, 0.5, "centralized", 1), "c3": (1, 4096, 100, 0.5, "sequential", 10),

@@ -1,5 +1,5 @@
 import math, sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
 N, T = 4096, 100
 s = BatchSolver(1, N, T, 0.5)

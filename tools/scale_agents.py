@@ -1,7 +1,7 @@
 """Per-kernel time versus agents per GPU (single-track, H=100): shows which kernels are latency-bound
 (time flat in N) and where the chip starts to fill."""
 import math, sys
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
 T = 100
 for N in (1024, 2048, 4096, 8192, 16384, 32768):

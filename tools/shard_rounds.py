@@ -1,7 +1,7 @@
 """Rounds and time of every rank's shard for the weak-scaling bench (4096 agents per GPU, agent i of N_total at
 theta = 2*pi*i/N_total): what the slowest rank of an N-GPU run will take, measured one shard at a time on one GPU."""
 import math, sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_agent_solver_amd.batch import BatchSolver, single_track_x0
 PER = 4096
 for world in (1, 2, 4, 8):
