@@ -10,17 +10,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+argv = list(sys.argv[1:])
+alg_out = None
+if "--algorithmic" in argv:
+    i = argv.index("--algorithmic")
+    alg_out = argv[i + 1]
+    del argv[i:i + 2]
+args = argv
 wname = args[0] if args else "c3"
 w = dict(bench.WORKLOADS[wname])
 N = int(args[1]) if len(args) > 1 else w["agents"]
 s = bench.make_solver(w, N, 0, N, 0)
-if "--algorithmic" in sys.argv:
+if alg_out:
     s.set_profiling(True)
 s.reset_stats()
 bench.one_step(s, w)
 st = s.stats()
 print("workload", wname, "agents", N, "iterations", st["agent_iterations"], "rounds", st["batch_iterations"])
-if "--algorithmic" in sys.argv:
-    out = sys.argv[sys.argv.index("--algorithmic") + 1]
-    json.dump({"workload": wname, "agents": N, "stats": st, "kernels": s.kernel_times()}, open(out, "w"), indent=1)
+if alg_out:
+    json.dump({"workload": wname, "agents": N, "stats": st, "kernels": s.kernel_times()}, open(alg_out, "w"), indent=1)
