@@ -156,9 +156,24 @@ template <class M>
 struct BackwardTileLayout {
   using L = DerivLayout<M>;
   static constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
+  // LDS tile of one agent, in doubles.  Two rules shape it (MI355X_MICROARCH.md, LDS): a ds_write_b64 is served in four
+  // groups of 16 consecutive lanes -- one agent's 16 lanes -- over 32 dword banks, so the 16 lanes must hit 16 different
+  // doubles modulo 16; and lanes that have nothing to write must NOT share one dummy address (sixteen lanes on one
+  // address cost fifteen extra cycles: that, not the operand reads, was the 64 conflict cycles per time step of round 1).
+  // Hence a PAD region of 16 doubles at an offset that is a multiple of 16: an idle lane writes pad_at(x) where x is the
+  // address it would have had if the item list went on -- the residues modulo 16 of one instruction stay a permutation.
   static constexpr int oD = 0, oV = oD + ND, oVx = oV + NX * NX, oAtV = oVx + NX, oBtV = oAtV + NX * NX, oQx = oBtV + NU * NX,
-                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oDummy = oQuu + NU * NU, oNegZero = oDummy + 1, kEnd = oNegZero + 1;
-  static constexpr int STRIDE = (kEnd % 32 == 0) ? kEnd + 2 : kEnd;     // keep agents on different LDS banks
+                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oL = oQuu + NU * NU, oNegZero = oL + NU * NU,
+                       kUsed = oNegZero + 1, oPad = (kUsed + 15) / 16 * 16, kEnd = oPad + 16;
+  // agents of one 32-lane read group (two tiles) kStrideMod doubles apart modulo 32
+#if defined(MAS_BWD_STRIDE_MOD32)
+  static constexpr int kStrideMod = MAS_BWD_STRIDE_MOD32;
+#else
+  static constexpr int kStrideMod = 16;
+#endif
+  static constexpr int STRIDE = kEnd + ((kStrideMod - kEnd % 32) % 32 + 32) % 32;
+  static_assert(STRIDE >= kEnd, "tile stride");
+  __host__ __device__ static constexpr int pad_at(int x) { return oPad + (x & 15); }
 };
 
 // Per time step the wavefront makes three passes over its four LDS tiles, every lane running the
@@ -228,6 +243,15 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   constexpr int APW = 64 / LPA;                     // agents per wavefront (LPA lanes per agent)
   constexpr int LL = 16;                            // ladder width: rungs tried at once (lanes beyond LL repeat rung lane % LL)
   static_assert(LPA >= LL && 64 % LPA == 0, "lanes per agent");
+  // kLocalQuu (experiment, off): every lane forms q_uu itself right after pass 1, so that the LLT / ladder chain starts one
+  // LDS round trip earlier and pass 2 runs in its shadow.  Measured on C3: 142 us per launch against 132 us -- the 36 extra
+  // FP64 instructions per lane cost more than the round trip saves; the kernel is bound by dependent-issue latency
+  // (7 cycles per dependent FP64 instruction, ~255 of them per step), not by LDS.
+#if defined(MAS_BWD_LOCAL_QUU)
+  constexpr bool kLocalQuu = (MAS_BWD_LOCAL_QUU != 0) && NU <= 2;
+#else
+  constexpr bool kLocalQuu = false;
+#endif
   __shared__ double lds[APW * TL::STRIDE];
 
   const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
@@ -250,11 +274,11 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
 
   // ---- loop-invariant operand addresses of this lane's work items (tile-relative, in doubles)
   constexpr int W1 = NX * NX + NU * NX + NX + NU, R1 = (W1 + LPA - 1) / LPA;
-  constexpr int W2 = NX * NX + NU * NX + NU * NU, R2 = (W2 + LPA - 1) / LPA;
+  constexpr int W2 = NX * NX + NU * NX + (kLocalQuu ? 0 : NU * NU), R2 = (W2 + LPA - 1) / LPA;
   int p1[R1], q1[R1], b1[R1], o1[R1];              // pass 1: out = [bias +] sum_k T[p+k] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R1; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, qa = 0, ba = TL::oNegZero, oa = TL::oDummy;
+    int pa = 0, qa = 0, ba = TL::oNegZero, oa = TL::pad_at(TL::oAtV + w);     // idle lanes of the last round: own pad slot
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
     else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
     else if (w < NX * NX + NU * NX + NX) { const int i = w - NX * NX - NU * NX; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }
@@ -264,28 +288,29 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
   int p2[R2], ps2[R2], q2[R2], b2[R2], o2[R2];     // pass 2: out = bias + sum_k T[p + k*ps] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R2; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, ps = 1, qa = 0, ba = 0, oa = TL::oDummy;
+    int pa = 0, ps = 1, qa = 0, ba = 0, oa = TL::pad_at(TL::oQxx + w);
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oAtV + i; ps = NX; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLxx + w; oa = TL::oQxx + w; }
     else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLux + e; oa = TL::oQux + e; }
     else if (w < W2) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
     p2[r] = pa; ps2[r] = ps; q2[r] = qa; b2[r] = ba; o2[r] = oa;
   }
 
-  // software pipeline: the four tiles of step t-1 travel HBM -> registers while step t is computed.
-  // Per chunk the 4 tiles are 4*cw contiguous doubles (tile_offset); lane tid < 4*cw takes one of them.  No
-  // predication: a surplus lane of the short last chunk re-reads the chunk's last element and publishes it to
-  // its tile's dummy slot, so fetch and publish are NCH loads and NCH LDS writes with loop-invariant per-lane
-  // offsets and one uniform base pointer that steps back by Np*ND doubles per time step.
+  // software pipeline: the tiles of step t-1 travel HBM -> registers while step t is computed.  Every lane works for
+  // its OWN agent: lane l fetches element c*16 + l of its agent's tile (chunk c holds the 4 agents' cw-element pieces back
+  // to back, tile_offset) and publishes it to its agent's LDS tile, so each 16-lane write group fills 16 consecutive
+  // doubles.  No predication: a surplus lane of the short last chunk re-reads the piece's last element and publishes it to
+  // its pad slot; fetch and publish are NCH loads and NCH LDS writes with loop-invariant per-lane offsets and one uniform
+  // base pointer that steps back by Np*ND doubles per time step.
   constexpr int NCH = (ND + kTileChunk - 1) / kTileChunk;
+  static_assert(kTileChunk <= LPA, "one lane per chunk element");
   double pre[NCH];
   unsigned fetch_off[NCH]; int publish_at[NCH];
   MAS_UNROLL for (int c = 0; c < NCH; ++c) {
     const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
-    const bool mine = tid < APW * cw;
-    const int idx = mine ? tid : APW * cw - 1;
-    const int sl = idx / cw;
-    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a0 % 64) * cw + idx) * sizeof(double));
-    publish_at[c] = mine ? sl * TL::STRIDE + TL::oD + c * kTileChunk + (idx - sl * cw) : slot * TL::STRIDE + TL::oDummy;
+    const bool mine = lane < cw;
+    const int e = mine ? lane : cw - 1;
+    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
+    publish_at[c] = slot * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
   }
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
   const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
@@ -331,9 +356,18 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p1[r] + k] * T[q1[r] + k];
         res[r] = T[b1[r]] + s;                                        // items without a bias term add -0.0
       }
-      MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // padding items write the tile's dummy slot
+      MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // idle lanes write their own pad slot
     }
     __syncthreads();
+    double quu[NU * NU], qu[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU];
+    if constexpr (kLocalQuu) {                                        // q_uu = l_uu + (B^T V) B, :119, every lane for itself
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+        const int i = e % NU, j = e / NU;
+        double s = 0.0;
+        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[TL::oBtV + i + k * NU] * T[TL::oD + L::oB + j * NX + k];
+        quu[e] = T[TL::oD + L::oLuu + e] + s;
+      }
+    }
     // ---- pass 2 (second factors of ilqr.hpp:117-119)
     {
       double res[R2];
@@ -344,13 +378,12 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       }
       MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
     }
-    __syncthreads();
+    if constexpr (!kLocalQuu) {
+      __syncthreads();
+      MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
+    }
     // ---- pass 3 (ilqr.hpp:172-192)
     {
-      double quu[NU * NU], qu[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU];
-      MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
-      MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
-
       // LLT + x10 regularisation ladder (:172-182), the 16 lanes of an agent trying 16 consecutive
       // rungs at once: lane r adds reg_0 .. reg_{r-1} to the diagonal in the reference's order (so
       // its matrix is bit-identical to what the sequential ladder holds at rung r) and factorises it;
@@ -414,11 +447,12 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
           }
         }
         }
-        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oAtV + i] = Lfac[i]; }   // oAtV is dead after pass 2
+        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oL + i] = Lfac[i]; }
         if (lane == 0 && (!SharedLadder || a == 0)) regs += win;         // the stacked solve counts its rungs once (agent 0)
-        __syncthreads();
-        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oAtV + i];
+        __syncthreads();                                                 // also orders the pass-2 outputs before the reads below
+        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oL + i];
       }
+      MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
       llt_solve_identity<NU>(Lfac, ninv);                           // Quu_reg^-1, :183
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) ninv[i] = -ninv[i];
       MAS_UNROLL for (int m = 0; m < NU; ++m) {                     // k = -Quu^-1 q_u, :185
@@ -467,7 +501,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: a lower or diagonal
         // entry averages the old values, an upper entry sees its (already rewritten) mirror
         const double sym = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));
-        T[live ? (TL::oV + w) : TL::oDummy] = sym;
+        T[live ? (TL::oV + w) : TL::pad_at(TL::oV + w)] = sym;
         // the lanes of the first tile column (j == 0) also own gain column i and v_x entry i, :186,188-189
         {
           double vxi;
@@ -478,7 +512,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
           s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
           vxi = vxi + s;
           const bool owner = live && j == 0;
-          T[owner ? (TL::oVx + i) : TL::oDummy] = vxi;
+          T[owner ? (TL::oVx + i) : TL::pad_at(TL::oVx + w)] = vxi;
           MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[r][m], Ki[m]);
         }
       }

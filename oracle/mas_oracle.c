@@ -524,6 +524,11 @@ static void gains_and_value(step_ws* w, double* k, double* K, double* vx, double
  * it only guards the oracle against a logic error. */
 #define MAS_REG_LADDER_MAX 400
 
+/* diagnostic: how many rungs each (solve, time step) needed -- index min(rungs, 63); not thread-exact (plain increments from the
+ * OpenMP loop), good enough for a histogram; read and cleared through mas_oracle_rung_histogram */
+static long g_rung_hist[64];
+void mas_oracle_rung_histogram(long* out, int clear) { for (int i = 0; i < 64; ++i) { if (out) out[i] = g_rung_hist[i]; if (clear) g_rung_hist[i] = 0; } }
+
 /* LLT with the x10 regularisation ladder, ilqr.hpp:172-182.  Returns rungs used, or -1. */
 static int llt_ladder(step_ws* w) {
   const int nu = w->nu;
@@ -539,6 +544,7 @@ static int llt_ladder(step_ws* w) {
     reg *= 10.0; ++rungs;
   }
   if (cur != acc) free(cur);
+  if (rungs >= 0) g_rung_hist[rungs < 63 ? rungs : 63]++;
   return rungs;
 }
 
