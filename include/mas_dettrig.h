@@ -9,8 +9,15 @@
  * disagree in the last bit of sin/cos/tan now and then, so no GPU implementation can agree
  * with a glibc-linked CPU run to any useful tolerance -- unless both sides evaluate the
  * transcendental functions with the SAME sequence of IEEE-754 operations.  This header is
- * that sequence: only + - * / , rint and integer masks, no fma, no tables, no libm.  Compiled
- * with -ffp-contract=off it returns identical bits under gcc on x86-64 and hipcc on gfx950.
+ * that sequence: only + - * / , fma, rint and integer masks -- every one of them a correctly
+ * rounded IEEE-754-2008 operation -- no tables, no libm transcendental.  The fused multiply-adds
+ * are EXPLICIT (v_fma_f64 on gfx950; C99 fma() on the CPU, which glibc evaluates exactly, in
+ * hardware where the CPU has it); compiled with -ffp-contract=off, so that the compiler fuses
+ * nothing on its own, the header returns identical bits under gcc on x86-64 and hipcc on gfx950.
+ * (Round 1 of this header used no fma at all; the Horner steps then cost two dependent
+ * instructions each, and sin/cos/tan were two thirds of the line-search rollout's instructions.
+ * The reference calls glibc's sin/cos/tan, which use fma internally where the CPU has it: how a
+ * libm rounds inside is not part of the reference's arithmetic, only its <= 1 ulp result is.)
  *
  * WHAT.  Three-stage Cody-Waite reduction by pi/2 (33-bit pieces, exact products for
  * |n| < 2^20, i.e. |x| < 1.6e6), then degree-17 / degree-16 Taylor polynomials on
@@ -37,6 +44,7 @@
 #endif
 
 #define MAS_DT_MAX_ARG 1.6e6
+#define MAS_DT_FMA(a, b, c) __builtin_fma((a), (b), (c))   /* one rounding: RN(a*b + c) */
 
 /* reduce x to y0 + y1 in [-pi/4, pi/4] (y1 = tail), return the quadrant n mod 4 */
 MAS_DT_FN int mas_dt_rem_pio2(double x, double* y0, double* y1) {
@@ -45,12 +53,12 @@ MAS_DT_FN int mas_dt_rem_pio2(double x, double* y0, double* y1) {
   const double pio2_2 = 0x1.0b4611a600000p-34, pio2_2t = 0x1.3198a2e037073p-69;
   const double pio2_3 = 0x1.3198a2e000000p-69, pio2_3t = 0x1.b839a252049c1p-104;
   const double fn = rint(x * invpio2);
-  double r = x - fn * pio2_1;
-  double w = fn * pio2_1t;
-  double t = r;
-  w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
+  double r = MAS_DT_FMA(-fn, pio2_1, x);          /* fn * pio2_1 is exact (33-bit piece): same bits as x - fn*pio2_1 */
+  double w, t = r;
+  (void)pio2_1t;
+  w = fn * pio2_2; r = t - w; w = MAS_DT_FMA(fn, pio2_2t, -((t - r) - w));
   t = r;
-  w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
+  w = fn * pio2_3; r = t - w; w = MAS_DT_FMA(fn, pio2_3t, -((t - r) - w));
   *y0 = r - w;
   *y1 = (r - *y0) - w;
   return ((int)fn) & 3;
@@ -63,10 +71,11 @@ MAS_DT_FN double mas_dt_ksin(double x, double y) {
                S15 = -0x1.ae7f3e733b81fp-41, S17 = 0x1.952c77030ad4ap-49;
   const double z = x * x;
   double p = S17;
-  p = p * z + S15; p = p * z + S13; p = p * z + S11; p = p * z + S9; p = p * z + S7; p = p * z + S5;
+  p = MAS_DT_FMA(p, z, S15); p = MAS_DT_FMA(p, z, S13); p = MAS_DT_FMA(p, z, S11); p = MAS_DT_FMA(p, z, S9);
+  p = MAS_DT_FMA(p, z, S7); p = MAS_DT_FMA(p, z, S5);
   const double v = z * x;
   /* x + (v*(S3 + z*p) + y*(1 - z/2)) */
-  return x + (v * (S3 + z * p) + y * (1.0 - 0.5 * z));
+  return x + MAS_DT_FMA(v, MAS_DT_FMA(z, p, S3), y * (1.0 - 0.5 * z));
 }
 
 /* cos(x + y) for |x| <= pi/4 */
@@ -76,10 +85,11 @@ MAS_DT_FN double mas_dt_kcos(double x, double y) {
                C16 = 0x1.ae7f3e733b81fp-45;
   const double z = x * x;
   double q = C16;
-  q = q * z + C14; q = q * z + C12; q = q * z + C10; q = q * z + C8; q = q * z + C6; q = q * z + C4;
+  q = MAS_DT_FMA(q, z, C14); q = MAS_DT_FMA(q, z, C12); q = MAS_DT_FMA(q, z, C10); q = MAS_DT_FMA(q, z, C8);
+  q = MAS_DT_FMA(q, z, C6); q = MAS_DT_FMA(q, z, C4);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
-  return w + (((1.0 - w) - hz) + ((z * z) * q - x * y));
+  return w + (((1.0 - w) - hz) + MAS_DT_FMA(z * z, q, -(x * y)));
 }
 
 /* Arguments outside the reduction range (|x| > 1.6e6), NaN and Inf give NaN: a loud, and still
