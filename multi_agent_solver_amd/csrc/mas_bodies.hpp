@@ -284,6 +284,7 @@ struct SelectBody {
   // iteration; here the check for iteration i+1 is made at the end of iteration i (select), a few microseconds earlier.
   unsigned long long* solve_start = nullptr; double max_ms = 0.0;
   int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // "debug" trace: iteration number (0 = idle) and d_merit per agent
+  int* ended = nullptr;                // non-null: 1 for every agent whose solve ended in this iteration, else 0 (chained trust-region epilogue)
   MAS_HD bool out_of_time(int a) const {
     if (!solve_start) return false;
     const double elapsed_ms = static_cast<double>(static_cast<long long>(static_cast<double>(MAS_NOW_TICKS() - solve_start[a]) / kTicksPerMs));
@@ -302,6 +303,11 @@ struct SelectBody {
     return true;
   }
   MAS_HD int decide(int a) const {
+    const int r = decide_(a);
+    if (ended) ended[a] = (r == kConverged || r == kRetired || (r & kChained) != 0) ? 1 : 0;
+    return r;
+  }
+  MAS_HD int decide_(int a) const {
     if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
     if (!active[a]) { alpha_sel[a] = -1; if (dbg_iter) dbg_iter[a] = 0; return kIdle; }
     const double cur = merit[a];
@@ -480,6 +486,109 @@ struct TrustRegionBody {
       for (int r = 0; r < d.T * NU; ++r) MAS_AT(U, r, a) = MAS_AT(U_old, r, a);
       for (int r = 0; r < (d.T + 1) * NX; ++r) MAS_AT(X, r, a) = MAS_AT(X_old, r, a);
       cost[a] = cost_old[a]; radii[a] = radius * 0.5;
+    }
+  }
+};
+
+// -------------------------------------------------------------------------------------------
+// Trust-region epilogue for CHAINED solves (run_trust_region without a host barrier between outer iterations).
+// detail::run_trust_region (nash.hpp:182-248) treats every agent on its own: solve, measure the control step against
+// the agent's radius, scale it back and re-roll if it is too long, accept (radius x1.5) or revert (radius x0.5).  An
+// agent's outer iteration k+1 therefore depends on nothing but its own iteration k, so an agent whose solve ends in
+// some round runs its epilogue right there and goes on with its next solve in the following round.  Three kernels per
+// round, all of them no-ops for agents whose solve did not end in it (SelectBody::ended):
+//   TrustNormBody    lane = agent: step norm (serial sum in the reference's column-major order); a step inside the
+//                    radius is accepted / reverted at once, a longer one is queued for the re-roll
+//   TrustRerollBody  lane = queued agent: scaled step, rollout, cost, then accept / revert
+//   TrustCopyBody    lane = (agent, t): revert = restore the old trajectory, accept = make the new one the old one
+enum TrustVerdict : int { kTrustNone = 0, kTrustAccept = 1, kTrustRevert = 2, kTrustReroll = 3 };
+
+struct TrustState {
+  double* cost; double* merit; double* cost_old; double* radii;
+  int* verdict;                     // [Np] TrustVerdict of this round
+  // accept / revert, nash.hpp:228-243; the next solve's current_merit is the objective of the trajectory it starts from
+  MAS_HD void finish(int a, double cand_cost, double radius) const {
+    if (cand_cost < cost_old[a]) { cost[a] = cand_cost; merit[a] = cand_cost; cost_old[a] = cand_cost; radii[a] = radius * 1.5; verdict[a] = kTrustAccept; }
+    else { cost[a] = cost_old[a]; merit[a] = cost_old[a]; radii[a] = radius * 0.5; verdict[a] = kTrustRevert; }
+  }
+};
+
+template <class M>
+struct TrustNormBody {
+  Dims d; const int* ended; const double* U; const double* U_old; TrustState ts;
+  double* scale_out;                // [Np] radius / norm for the queued agents
+  int* roll_list; int* roll_count;  // agents whose step leaves the trust region, compacted
+  MAS_HD void operator()(int a) const {
+    constexpr int NU = M::NU;
+    if (!ended[a]) { ts.verdict[a] = kTrustNone; return; }
+    const double radius = ts.radii[a];
+    double ss = 0.0;                                   // delta.norm(): Frobenius, column-major order (nash.hpp:216-217)
+    const int R = d.T * NU;
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {                       // eight loads in flight, the additions stay in order
+      double dl[8];
+      MAS_UNROLL for (int q = 0; q < 8; ++q) dl[q] = MAS_AT(U, r + q, a) - MAS_AT(U_old, r + q, a);
+      MAS_UNROLL for (int q = 0; q < 8; ++q) ss += dl[q] * dl[q];
+    }
+    for (; r < R; ++r) { const double dl = MAS_AT(U, r, a) - MAS_AT(U_old, r, a); ss += dl * dl; }
+    const double norm = sqrt(ss);
+    if (norm > radius) {
+      scale_out[a] = radius / norm;
+      ts.verdict[a] = kTrustReroll;
+#if defined(__HIP_DEVICE_COMPILE__)
+      roll_list[atomicAdd(roll_count, 1)] = a;
+#else
+      roll_list[(*roll_count)++] = a;
+#endif
+    } else {
+      ts.finish(a, ts.cost[a], radius);
+    }
+  }
+};
+
+template <class M>
+struct TrustRerollBody {
+  Dims d; double dt; ModelParams P;
+  const double* x0; double* X; double* U; const double* U_old; const double* scale; TrustState ts;
+  const int* roll_list; const int* roll_count;
+  MAS_HD void operator()(int slot) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (slot >= *roll_count) return;
+    const int a = roll_list[slot];
+    const double sc = scale[a];
+    double x[NX], xn[NX], u[NU];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(X, i, a) = x[i]; }
+    double c = 0.0;
+    for (int t = 0; t < d.T; ++t) {                    // cand_u = old_u + scale * delta; cand_x = rollout; cand_cost = objective (nash.hpp:219-226)
+      MAS_UNROLL for (int i = 0; i < NU; ++i) {
+        const double uo = MAS_AT(U_old, t * NU + i, a);
+        u[i] = uo + sc * (MAS_AT(U, t * NU + i, a) - uo);
+        MAS_AT(U, t * NU + i, a) = u[i];
+      }
+      c += M::stage_cost(x, u, t, P);
+      rk4_step<M>(x, u, dt, xn, P);
+      MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = xn[i]; MAS_AT(X, (t + 1) * NX + i, a) = x[i]; }
+    }
+    c += M::terminal_cost(x, P);
+    ts.finish(a, c, ts.radii[a]);
+  }
+};
+
+template <class M>
+struct TrustCopyBody {
+  Dims d; const int* verdict;
+  double* X; double* U; double* X_old; double* U_old;
+  int* roll_count;                  // reset here (last kernel of the round's epilogue) for the next round's TrustNormBody
+  MAS_HD void operator()(int a, int t) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (a == 0 && t == 0) *roll_count = 0;
+    const int v = verdict[a];
+    if (v == kTrustAccept) {                           // the accepted trajectory is what the next outer iteration measures its step against
+      MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(X_old, t * NX + i, a) = MAS_AT(X, t * NX + i, a);
+      if (t < d.T) { MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(U_old, t * NU + i, a) = MAS_AT(U, t * NU + i, a); }
+    } else if (v == kTrustRevert) {
+      MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(X, t * NX + i, a) = MAS_AT(X_old, t * NX + i, a);
+      if (t < d.T) { MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(U, t * NU + i, a) = MAS_AT(U_old, t * NU + i, a); }
     }
   }
 };

@@ -202,11 +202,21 @@ class SolverImpl final : public SolverBase {
     ensure_initialized();
     ensure_snapshots();
     fill(radii, 1.0);
-    for (int outer = 0; outer < max_outer; ++outer) {
-      be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
-      be.d2d(cost_old, cost, sizeof(double) * d.Np);
-      solve_all();
-      be.template launch_1d<1>("trust_region", TrustRegionBody<M>{d, dt, P, x0, X, U, cost, X_old, U_old, cost_old, radii}, d.N);
+    // An agent's outer iteration k+1 (solve, then the trust-region test on its own step) depends only on its own
+    // iteration k, so the outer iterations are chained on the device like the solves of the sequential strategy: an agent
+    // whose solve ends runs its epilogue in that round (TrustNormBody / TrustRerollBody / TrustCopyBody) and starts its
+    // next solve in the following one -- no host barrier, no waiting for the slowest agent of every outer iteration.  The
+    // multiplier update between solves and the per-agent debug trace need the host between solves and keep the loop.
+    const bool chain = max_outer > 1 && !(kConstrained && al_enabled) && !debug;
+    if (chain) {
+      snapshot_old();
+      solve_all(max_outer, /*trust_epilogue=*/true);
+    } else {
+      for (int outer = 0; outer < max_outer; ++outer) {
+        snapshot_old();
+        solve_all();
+        be.template launch_1d<1>("trust_region", TrustRegionBody<M>{d, dt, P, x0, X, U, cost, X_old, U_old, cost_old, radii}, d.N);
+      }
     }
     last_total_valid = false;
   }
@@ -351,6 +361,10 @@ class SolverImpl final : public SolverBase {
     X_old = dalloc((d.T + 1) * NX * d.Np); U_old = dalloc(static_cast<size_t>(d.T) * NU * d.Np); cost_old = dalloc(d.Np);
     U_cand = dalloc(static_cast<size_t>(d.T) * NU * d.Np);
   }
+  void snapshot_old() {
+    be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
+    be.d2d(cost_old, cost, sizeof(double) * d.Np);
+  }
   bool timed_out(std::chrono::steady_clock::time_point t0) const {
     // ilqr.hpp:84-90: elapsed truncated to whole milliseconds, compared with max_ms.  All solves of a
     // batch start together, so one host clock stands for every agent's.
@@ -493,8 +507,12 @@ class SolverImpl final : public SolverBase {
   // results are unaffected.  (Agent ranges on separate streams were also tried: no gain at 4096 agents, the
   // round is bound by each agent's own sequential chain -- DESIGN.md section 4.)
   // n_solves > 1: every agent performs that many consecutive solves (SelectBody::begin_chain)
-  void solve_all(int n_solves = 1) {
+  // trust_epilogue: every solve of the chain is followed by the agent's trust-region test (run_trust_region)
+  void solve_all(int n_solves = 1, bool trust_epilogue = false) {
     ensure_initialized();
+    if (trust_epilogue && !trust_verdict) {
+      trust_verdict = ialloc(d.Np); trust_ended = ialloc(d.Np); trust_roll_list = ialloc(d.Np); trust_roll_count = ialloc(16); trust_scale = dalloc(d.Np);
+    }
     // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78).  After
     // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
     // rollout and cost (same kernels, same arithmetic, bit for bit), so it is only redone when the
@@ -544,9 +562,15 @@ class SolverImpl final : public SolverBase {
                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
                            al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : live_list,
                            n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
-                           debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr};
+                           debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr, trust_epilogue ? trust_ended : nullptr};
       be.template launch_1d<1>("select", sel, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      if (trust_epilogue) {
+        const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
+        be.template launch_1d<1>("trust_norm", TrustNormBody<M>{d, trust_ended, U, U_old, ts, trust_scale, trust_roll_list, trust_roll_count}, d.N);
+        be.template launch_1d<1>("trust_reroll", TrustRerollBody<M>{d, dt, P, x0, X, U, U_old, trust_scale, ts, trust_roll_list, trust_roll_count}, d.N);
+        be.template launch_2d<4>("trust_copy", TrustCopyBody<M>{d, trust_verdict, X, U, X_old, U_old, trust_roll_count}, d.N, d.T + 1);
+      }
       if constexpr (kConstrained) {
         if (al_round)
           be.template launch_1d<1>("al_update", ALUpdateBody<M>{d, P, tolerance, max_iterations, ALParams{penalty_increase, constraint_tolerance, inequality_activation_tolerance},
@@ -644,6 +668,8 @@ class SolverImpl final : public SolverBase {
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   int *live_list = nullptr, *live_count0 = nullptr;   // agents still active, compacted by select; count of round 0 (= N)
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
+  int *trust_verdict = nullptr, *trust_ended = nullptr, *trust_roll_list = nullptr, *trust_roll_count = nullptr;   // chained trust-region epilogue
+  double *trust_scale = nullptr;
   unsigned long long* solve_start = nullptr;          // tick at which each agent's current solve began (finite max_ms only)
   int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // per-agent trace of the last round ("debug")
   unsigned long long* ladder_sync = nullptr; bool ladder_error_pending = false;   // rung agreement of the centralised backward pass (LadderSync)

@@ -199,3 +199,18 @@ def test_debug_key_prints_the_reference_trace(hostcheck_lib, oracle, capfd):
         assert [int(ln.split("iLQR iter ")[1].split(":")[0]) for ln in its] == list(range(len(its)))
         last = its[-1]
         assert f"cost={o['cost'][a]:.6g}" in last and "d_merit=" in last and last.endswith("eq_violation=0 ineq_violation=0")
+
+
+@pytest.mark.parametrize("strategy,outer", [("sequential", 4), ("trustregion", 4)])
+def test_perturbed_agents_finish_their_solves_in_different_rounds(hostcheck_lib, oracle, strategy, outer):
+    """chained outer iterations (no host barrier between them): agents with different iteration counts are in different
+    outer iterations at the same time; for the trust-region strategy every agent runs its epilogue (step norm, re-roll
+    of a too-long step, accept / revert) in the round its own solve ends"""
+    N, T = 40, 30
+    rng = np.random.default_rng(0)
+    x0 = oracle.single_track_x0(N) + 0.1 * rng.standard_normal((N, 4))
+    U0 = 0.05 * rng.standard_normal((N, T, 2))
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, U0, T, 0.5, strategy, max_outer=outer)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, U0, T, 0.5, strategy=strategy, max_outer=outer)
+    _same(e, o)
+    assert len(set(o["iters"].tolist())) > 3
