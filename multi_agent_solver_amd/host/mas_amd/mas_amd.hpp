@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 #include <optional>
@@ -99,6 +100,38 @@ class Batch {
   mas_hip_solver* h_ = nullptr;
 };
 
+// What a device handle is made for: everything mas_hip_create takes.  Two OCPs with equal keys can use one handle
+// (only x0, the controls and the solver parameters differ between calls).
+struct BatchKey {
+  ModelDescriptor model; int n_agents = 0, horizon = 0; double dt = 0.0;
+  std::optional<Control> lb, ub;
+  bool operator==(const BatchKey& o) const {
+    return model == o.model && n_agents == o.n_agents && horizon == o.horizon && dt == o.dt && lb == o.lb && ub == o.ub;
+  }
+};
+
+// One-entry handle cache.  A `mas_hip_solver` owns ~30 device allocations and a stream; creating and destroying one per
+// solve(OCP&) made the N = 1 drop-in path (reference usage: nash.hpp:59-64 calls solve() on the same solver object once
+// per outer iteration; examples/pendulum_swing_up.cpp:158) pay ~1 ms of hipMalloc / hipFree per call.  The cache keeps
+// the last handle and reuses it while the key matches.  MAS_AMD_NO_HANDLE_CACHE=1 restores create-per-call (used to
+// measure the difference).
+class BatchCache {
+ public:
+  Batch& get(const BatchKey& key) {
+    static const bool disabled = [] { const char* e = std::getenv("MAS_AMD_NO_HANDLE_CACHE"); return e && e[0] == '1'; }();
+    if (disabled || !batch_ || !(key_ == key)) {
+      batch_.reset();                                // free the old device memory before allocating the new handle
+      batch_ = std::make_shared<Batch>(key.model, key.n_agents, key.horizon, key.dt, key.lb, key.ub);
+      key_ = key;
+    }
+    return *batch_;
+  }
+  void clear() { batch_.reset(); }
+ private:
+  std::shared_ptr<Batch> batch_;
+  BatchKey key_;
+};
+
 }  // namespace detail
 
 // ------------------------------------------------------------------------------ OCP ------
@@ -130,6 +163,7 @@ struct OCP {
   void initialize_problem() {
     if (initial_controls.rows() != control_dim || initial_controls.cols() != horizon_steps)
       initial_controls = ControlTrajectory::Zero(control_dim, horizon_steps);
+    // (called once per OCP: a handle of its own, released on return; repeated solves reuse iLQR's cached handle)
     detail::Batch b(model, 1, horizon_steps, dt, input_lower_bounds, input_upper_bounds);
     b.check(mas_hip_set_initial_states_host(b.get(), initial_state.data()), "set_initial_states");
     b.check(mas_hip_set_controls_host(b.get(), initial_controls.data.data()), "set_controls");
@@ -163,6 +197,12 @@ struct OCP {
 class iLQR {
  public:
   iLQR() = default;                                // defaults 50 / 1e-6 / inf live in the library (ilqr.hpp:26-37)
+  // copies are independent solver objects (the reference stores them in std::vector<Solver>, nash.hpp:78-83, and calls
+  // them from different OpenMP threads): a copy starts without a device handle of its own, it never shares one
+  iLQR(const iLQR& o) : last_iterations(o.last_iterations), last_exit(o.last_exit), params_(o.params_) {}
+  iLQR& operator=(const iLQR& o) { if (this != &o) { params_ = o.params_; last_iterations = o.last_iterations; last_exit = o.last_exit; cache_.clear(); } return *this; }
+  iLQR(iLQR&&) = default;
+  iLQR& operator=(iLQR&&) = default;
   void set_params(const SolverParams& params) {
     params.at("max_iterations");                   // the reference uses params.at(): std::out_of_range if absent
     params.at("tolerance");
@@ -171,8 +211,11 @@ class iLQR {
   }
   const SolverParams& params() const { return params_; }
 
-  void solve(OCP& problem) {                       // ilqr.hpp:58-273 on a one-agent batch
-    detail::Batch b(problem.model, 1, problem.horizon_steps, problem.dt, problem.input_lower_bounds, problem.input_upper_bounds);
+  // ilqr.hpp:58-273 on a one-agent batch.  The device handle is kept between calls (resize_buffers of the reference
+  // likewise only reallocates when the problem's shape changes, ilqr.hpp:277-377); like the reference's solver object it
+  // also keeps the augmented-Lagrangian multipliers and penalty across calls (ilqr.hpp:415-421).
+  void solve(OCP& problem) {
+    detail::Batch& b = cache_.get({problem.model, 1, problem.horizon_steps, problem.dt, problem.input_lower_bounds, problem.input_upper_bounds});
     b.set_params(params_);
     if (problem.best_controls.rows() != problem.control_dim || problem.best_controls.cols() != problem.horizon_steps)
       problem.best_controls = ControlTrajectory::Zero(problem.control_dim, problem.horizon_steps);
@@ -188,6 +231,7 @@ class iLQR {
   int last_iterations = 0, last_exit = 0;          // extension: the reference exposes neither
  private:
   SolverParams params_;
+  detail::BatchCache cache_;
 };
 
 using Solver = std::variant<iLQR>;                 // solvers/solver.hpp:17-22 (cgd / osqp are out of scope)

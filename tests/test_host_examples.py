@@ -121,3 +121,18 @@ def test_mixed_models_are_split_into_homogeneous_batches(exe_dir, oracle, strate
             assert model == 2 and cost == o_lq["cost"][0] and iters == o_lq["iters"][0]
         total += cost
     assert float(lines[0].split("cost=")[1]) == total
+
+
+@pytest.mark.gpu
+def test_repeated_solves_reuse_the_device_handle(exe_dir):
+    """VERDICT r1: iLQR::solve(OCP&) kept creating and destroying a device handle per call.  Same results either way;
+    the cached handle must not be slower (measured: INTEGRATION.md section 3)."""
+    exe = os.path.join(exe_dir, "solve_reuse_timing")
+    a = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=600)
+    b = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=600, env=dict(os.environ, MAS_AMD_NO_HANDLE_CACHE="1"))
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    fa = dict(kv.split("=") for kv in a.stdout.split())
+    fb = dict(kv.split("=") for kv in b.stdout.split())
+    assert fa["cost"] == fb["cost"] and fa["iterations_last_call"] == fb["iterations_last_call"] == "1"
+    assert float(fa["ms_per_call"]) < float(fb["ms_per_call"])
+    print("cached", fa["ms_per_call"], "ms/call; create-per-call", fb["ms_per_call"], "ms/call")
