@@ -152,6 +152,7 @@ class SolverImpl final : public SolverBase {
   void set_initial_states(const double* src, bool device_ptr) override {
     upload(src, static_cast<size_t>(d.N) * NX, device_ptr);
     be.template launch_2d<1>("aos_to_soa", AosToSoaBody{d, NX, stage, x0, 1}, d.N, 1);
+    be.zero(iters_total, sizeof(int) * d.Np);            // new initial states = a new problem: per-agent iteration counts restart
     have_x0 = true; initialized = false; rollout_consistent = false;
   }
   void set_controls(const double* src, bool device_ptr) override {
@@ -384,8 +385,9 @@ class SolverImpl final : public SolverBase {
   // LDS (mas_kernels_hip.hpp); the host emulation replays the plain body
   // live_count != nullptr: walk the compacted list of active agents (live_list) instead of the active flags
   void launch_sweep(double bytes) { launch_sweep(bytes, 0, d.N); }
-  void launch_sweep(double bytes, int lo, int hi, const int* live_count = nullptr) {
-    (void)live_count;
+  // slots: with a live list, an upper bound of its length (the grid covers that many list slots)
+  void launch_sweep(double bytes, int lo, int hi, const int* live_count = nullptr, int slots = 0) {
+    (void)live_count; (void)slots;
 #if defined(MAS_HOST_EMULATION)
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
 #else
@@ -395,7 +397,7 @@ class SolverImpl final : public SolverBase {
     }
     be.begin("sweep", bytes);
     unsigned long long* stamp = nullptr;
-    const dim3 grid((hi - lo + 63) / 64, (d.T + 3) / 4);
+    const dim3 grid(((live_count ? slots : hi - lo) + 63) / 64, (d.T + 3) / 4);
     if (be.profiling) {                                   // in-kernel REFCLK stamps for the roofline kernel
       const size_t per_launch = 2 * static_cast<size_t>(grid.x) * grid.y;
       if (!sweep_stamps) { stamp_capacity = per_launch * kMaxStampedLaunches; sweep_stamps = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * stamp_capacity)); }
@@ -553,7 +555,10 @@ class SolverImpl final : public SolverBase {
       // augmented-Lagrangian update deciding termination after select, the list is not built and the flags are used
       const bool al_round = kConstrained && al_enabled;
       const int* live = al_round ? nullptr : (r == 0 ? live_count0 : reinterpret_cast<const int*>(counters + 2 * ((r - 1) % kCounterRing)));
-      launch_sweep(sweep_bytes(), 0, d.N, live);
+      // grid: the live list only shrinks during a chain of solves, so the last count the host has read back bounds it from
+      // above -- workgroups beyond the list would each be dispatched only to exit, and 1,500 of those cost a tail-round sweep
+      // more than its few live workgroups do
+      launch_sweep(sweep_bytes(), 0, d.N, live, live ? static_cast<int>(live_upper) : d.N);
       launch_backward(backward_bytes(), 0, d.N);
       be.template launch_2d_range<1>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
       long long* ctr = counters + 2 * (r % kCounterRing);
@@ -582,6 +587,7 @@ class SolverImpl final : public SolverBase {
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
     };
     long long n_before = d.N;
+    live_upper = d.N;
     int enq = 0, rounds_this_solve = 0;
     // the first check of a solve sees elapsed_ms == 0, so only a negative budget stops it before its first iteration
     if (max_iterations > 0 && !(timed && 0.0 > max_ms)) { enqueue(0); enq = 1; }
@@ -598,6 +604,7 @@ class SolverImpl final : public SolverBase {
       be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_before));
       for (size_t q = marks[r & 1].s0; q < marks[r & 1].s1; ++q) stamp_launches[q].bytes *= static_cast<double>(n_before);
       n_before = n_after;
+      live_upper = std::max<long long>(n_after, 1);
       if (n_after == 0) {                            // a round enqueued ahead runs on zero agents: nothing to account
         if (enq > r + 1) { be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0); for (size_t q = marks[(r + 1) & 1].s0; q < marks[(r + 1) & 1].s1; ++q) stamp_launches[q].bytes = 0.0; }
         break;
@@ -689,6 +696,7 @@ class SolverImpl final : public SolverBase {
   typename Backend::Event round_ev[2]{};
   bool round_events_made = false;
   int last_solve_rounds = 0;
+  long long live_upper = 0;        // upper bound of the number of live agents in the round being enqueued
   HostStats stats;
 };
 
