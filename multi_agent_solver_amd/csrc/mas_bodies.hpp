@@ -51,6 +51,9 @@ MAS_HD void st_off(double* base, unsigned byte_off, double v) { *reinterpret_cas
 constexpr int kTileChunk = 16;
 // lanes that share one agent's backward recursion (mas_backward_tile_kernel): 16 or 32; 64 / this = agents per wavefront
 constexpr int kBackwardLanesPerAgent = 16;   // measured on C3: 16 -> 145 us per launch, 32 -> 165 us
+// centralised backward pass: wavefronts per workgroup.  Measured on C2 (256 agents, us per launch): 1 -> 416, 4 -> 293, 8 -> 330,
+// 16 -> 485: fewer arrivals per agreement against more wavefronts sharing a SIMD
+constexpr int kCentralWavesPerBlock = 4;
 MAS_HD size_t tile_offset(int nd, size_t Np, int t, int a, int e) {
   const int c = e / kTileChunk, cw = (nd - c * kTileChunk < kTileChunk) ? (nd - c * kTileChunk) : kTileChunk;
   return (static_cast<size_t>(t) * (Np / 64) + static_cast<size_t>(a / 64)) * 64 * nd + static_cast<size_t>(c) * kTileChunk * 64 +

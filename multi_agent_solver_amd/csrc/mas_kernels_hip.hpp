@@ -232,8 +232,12 @@ __device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned
   return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(agreed)));
 }
 
-template <class M, int LPA, bool SharedLadder = false>
-__global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
+// WPB = wavefronts per workgroup.  1 for the per-agent Nash path.  The shared ladder of the centralised strategy runs WPB > 1:
+// the rung masks of a workgroup's wavefronts are first combined through LDS (one s_barrier), and only ONE wavefront per
+// workgroup takes part in the cross-workgroup agreement, so 256 agents are 4-16 arrivals per time step instead of 64 --
+// and a problem that fits one workgroup needs no global agreement at all.
+template <class M, int LPA, bool SharedLadder = false, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
                                                                double* __restrict__ kff, double* __restrict__ Kfb,
                                                                long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n,
                                                                LadderSync sync) {
@@ -252,13 +256,26 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
 #else
   constexpr bool kLocalQuu = false;
 #endif
-  __shared__ double lds[APW * TL::STRIDE];
+  static_assert(WPB == 1 || SharedLadder, "several wavefronts per workgroup only for the shared ladder");
+  __shared__ double lds[WPB * APW * TL::STRIDE];
+  __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];   // rung masks of the workgroup's wavefronts, double-buffered by agreement parity
+  __shared__ unsigned blk_agreed[2];
+  unsigned agreement_parity = 0;
 
-  const int tid = threadIdx.x, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
-  const int a0 = lo + blockIdx.x * APW, a = a0 + slot;
+  const int wave = static_cast<int>(threadIdx.x) >> 6;    // 0 when WPB == 1
+  const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
+  const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
   const bool valid = (a < n) && active[a] != 0;
   if (!SharedLadder && __ballot(valid) == 0ull) return;   // uniform for the (single-wave) block; a shared ladder needs every wavefront
-  double* T = lds + slot * TL::STRIDE;
+  const int tile = wave * APW + slot;
+  double* T = lds + tile * TL::STRIDE;
+  // the tiles of a wavefront are private to it: what separates its LDS writes from its own later reads is the order in which
+  // one wavefront's LDS instructions execute, not a workgroup barrier (with one wavefront per workgroup __syncthreads()
+  // compiles to exactly that wait; with several it would be a real s_barrier nobody needs here)
+  auto wave_sync = [] {
+    if constexpr (WPB == 1) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
 
   if (!valid) {                                     // idle slot: finite operands (its lanes run the same code, results unused)
     for (int e = lane; e < TL::STRIDE; e += LPA) T[e] = 0.0;
@@ -310,7 +327,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
     const bool mine = lane < cw;
     const int e = mine ? lane : cw - 1;
     fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
-    publish_at[c] = slot * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
+    publish_at[c] = tile * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
   }
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
   const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
@@ -346,7 +363,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
     MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(goff[m]);
     MAS_UNROLL for (int r = 0; r < RMX; ++r) { MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(koff[r][m]); }
     fetch();
-    __syncthreads();
+    wave_sync();
 
     // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
     {
@@ -358,7 +375,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       }
       MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // idle lanes write their own pad slot
     }
-    __syncthreads();
+    wave_sync();
     double quu[NU * NU], qu[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU];
     if constexpr (kLocalQuu) {                                        // q_uu = l_uu + (B^T V) B, :119, every lane for itself
       MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
@@ -379,7 +396,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
       MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
     }
     if constexpr (!kLocalQuu) {
-      __syncthreads();
+      wave_sync();
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
     }
     // ---- pass 3 (ilqr.hpp:172-192)
@@ -410,7 +427,27 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
             unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
             if (!valid) field = 0xFFFFu;                                   // an idle slot never holds the others back
             MAS_UNROLL for (int sh = LPA; sh < 64; sh <<= 1) field &= static_cast<unsigned>(__shfl_xor(static_cast<int>(field), sh));
-            const unsigned agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
+            unsigned agreed;
+            if constexpr (WPB == 1) {
+              agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
+            } else {
+              // workgroup first (LDS + one barrier), then one wavefront per workgroup across workgroups (if there are several)
+              const unsigned par = agreement_parity; agreement_parity ^= 1u;
+              if (tid == 0) blk_field[par][wave] = field;
+              __syncthreads();
+              unsigned bf = 0xFFFFu;
+              MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
+              if (gridDim.x == 1) {
+                agreed = bf;
+              } else {
+                if (wave == 0) {
+                  const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
+                  if (tid == 0) blk_agreed[par] = g;
+                }
+                __syncthreads();
+                agreed = blk_agreed[par];
+              }
+            }
             if (agreed != 0u) { win = base + __builtin_ctz(agreed); break; }
             if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; break; }   // guard, never reached (see kRegLadderMax)
           }
@@ -449,7 +486,7 @@ __global__ void __launch_bounds__(64) mas_backward_tile_kernel(Dims d, ModelPara
         }
         if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oL + i] = Lfac[i]; }
         if (lane == 0 && (!SharedLadder || a == 0)) regs += win;         // the stacked solve counts its rungs once (agent 0)
-        __syncthreads();                                                 // also orders the pass-2 outputs before the reads below
+        wave_sync();                                                 // also orders the pass-2 outputs before the reads below
         MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oL + i];
       }
       MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];

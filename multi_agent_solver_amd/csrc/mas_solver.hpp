@@ -425,8 +425,17 @@ class SolverImpl final : public SolverBase {
       const LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
       constexpr int apw = 64 / kBackwardLanesPerAgent;
       be.begin("central_backward", bytes);
-      be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true>, dim3((d.N + apw - 1) / apw), dim3(64), d, P, X, D, kff, Kfb,
-                       reg_events, active, 0, static_cast<int>(d.N), sy);
+      const int wpb = central_waves_per_block();
+      auto launch = [&](auto kernel, int w) {
+        const int agents_per_block = apw * w;
+        be.launch_kernel(kernel, dim3((d.N + agents_per_block - 1) / agents_per_block), dim3(64 * w), d, P, X, D, kff, Kfb,
+                         reg_events, active, 0, static_cast<int>(d.N), sy);
+      };
+      if (wpb == 16) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 16>, 16);
+      else if (wpb == 8) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 8>, 8);
+      else if (wpb == 4) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 4>, 4);
+      else if (wpb == 2) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 2>, 2);
+      else launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 1>, 1);
       be.end();
       ladder_error_pending = true;
       return;
@@ -460,14 +469,25 @@ class SolverImpl final : public SolverBase {
   // partitioned device, e.g. CPX with 32 CUs, or a build with higher register use may not hold them); if they do not fit,
   // the single-workgroup CentralBackwardBody is used instead -- slower, but it cannot starve.  Work of OTHER streams or
   // processes on the device is outside what can be checked here: mas_hip.h states the exclusivity requirement.
+  // wavefronts per workgroup of the centralised backward pass (see mas_backward_tile_kernel): measured on C2
+  int central_waves_per_block() const {
+    if (const char* e = std::getenv("MAS_HIP_CENTRAL_WPB")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return v; }
+    return kCentralWavesPerBlock;
+  }
   bool ladder_resident() {
     if (ladder_resident_checked) return ladder_resident_ok;
     ladder_resident_checked = true;
     constexpr int apw = 64 / kBackwardLanesPerAgent;
-    const int grid = (d.N + apw - 1) / apw;
+    const int wpb = central_waves_per_block();
+    const int grid = (d.N + apw * wpb - 1) / (apw * wpb);
     int per_cu = 0; hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true>, 64, 0) != hipSuccess ||
-        hipGetDeviceProperties(&prop, be.device) != hipSuccess) { (void)hipGetLastError(); ladder_resident_ok = false; return false; }
+    hipError_t q = hipErrorUnknown;
+    if (wpb == 16) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 16>, 64 * 16, 0);
+    else if (wpb == 8) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 8>, 64 * 8, 0);
+    else if (wpb == 4) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 4>, 64 * 4, 0);
+    else if (wpb == 2) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 2>, 64 * 2, 0);
+    else q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 1>, 64, 0);
+    if (q != hipSuccess || hipGetDeviceProperties(&prop, be.device) != hipSuccess) { (void)hipGetLastError(); ladder_resident_ok = false; return false; }
     ladder_resident_ok = static_cast<long long>(per_cu) * prop.multiProcessorCount >= grid;
     if (const char* f = std::getenv("MAS_HIP_FORCE_SINGLE_WORKGROUP_CENTRAL")) { if (f[0] == '1') ladder_resident_ok = false; }   // tests: exercise the fallback
     return ladder_resident_ok;
