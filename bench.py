@@ -250,7 +250,7 @@ def utilisation_of(workload):
     if not sq:
         return None
     out = {"source": f"{src} (rocprofv3 --pmc, SQ counters of one strategy run; collected at {sq.get('commit', 'unknown commit')})"}
-    for name in ("backward", "forward", "sweep"):
+    for name in ("backward", "central_backward", "forward", "sweep"):
         k = sq.get("kernels", {}).get(name)
         if k and "derived" in k:
             out[name] = k["derived"]

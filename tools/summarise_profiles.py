@@ -23,7 +23,7 @@ KERNELS = (("sweep", ("mas_sweep_kernel", "SweepBody")), ("central_backward", ("
 
 
 def classify(name):
-    if "mas_backward_tile_kernel" in name and ", true>" in name.split("(")[0]:
+    if "mas_backward_tile_kernel" in name and ", true" in name.split("(")[0]:      # <Model, 16, true, WPB>: the shared ladder of the centralised strategy
         return "central_backward"
     for key, pats in KERNELS:
         if key == "central_backward":
@@ -34,6 +34,8 @@ def classify(name):
 
 
 def commit_id():
+    if os.environ.get("GRAFT_COMMIT"):
+        return os.environ["GRAFT_COMMIT"]
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
