@@ -25,7 +25,7 @@ EXPORTS = [
     "mas_hip_set_initial_states_device", "mas_hip_set_controls_device",
     "mas_hip_initialize_problem", "mas_hip_save_initial", "mas_hip_restore_initial",
     "mas_hip_solve", "mas_hip_run_sequential", "mas_hip_run_trust_region", "mas_hip_run_line_search",
-    "mas_hip_run_centralized",
+    "mas_hip_run_centralized", "mas_hip_run_centralized_dense",
     "mas_hip_get_solution_host", "mas_hip_get_solution_device", "mas_hip_total_cost",
     "mas_hip_set_cost_exchange", "mas_hip_get_trust_radii_host", "mas_hip_debug_backward_host",
     "mas_hip_get_stats", "mas_hip_reset_stats", "mas_hip_set_profiling", "mas_hip_get_kernel_times",
@@ -97,7 +97,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     lib.mas_hip_set_initial_states_device.argtypes = [vp, vp]
     lib.mas_hip_set_controls_device.argtypes = [vp, vp]
     for name in ("mas_hip_initialize_problem", "mas_hip_save_initial", "mas_hip_restore_initial", "mas_hip_solve",
-                 "mas_hip_run_centralized", "mas_hip_reset_stats"):
+                 "mas_hip_run_centralized", "mas_hip_run_centralized_dense", "mas_hip_reset_stats"):
         getattr(lib, name).argtypes = [vp]
     for name in ("mas_hip_run_sequential", "mas_hip_run_trust_region", "mas_hip_run_line_search",
                  "mas_hip_set_profiling"):

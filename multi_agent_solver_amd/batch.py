@@ -177,6 +177,10 @@ class BatchSolver:
     def run_centralized(self):
         self._check(self._lib.mas_hip_run_centralized(self._h))
 
+    def run_centralized_dense(self):
+        """the reference's literal stacked solve (FD of the summed cost), N <= 16"""
+        self._check(self._lib.mas_hip_run_centralized_dense(self._h))
+
     def run(self, strategy: str, max_outer: int = 10):
         if strategy == "sequential":
             self.run_sequential(max_outer)
@@ -186,6 +190,8 @@ class BatchSolver:
             self.run_line_search(max_outer)
         elif strategy == "centralized":
             self.run_centralized()
+        elif strategy == "centralized_dense":
+            self.run_centralized_dense()
         elif strategy == "single":
             self.solve()
         else:

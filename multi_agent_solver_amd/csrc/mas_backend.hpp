@@ -83,7 +83,7 @@ struct Backend {
   // one cooperating group of `n` lanes that needs block-wide reductions: emulated serially by
   // the body itself (see CentralBackwardBody)
   template <class F>
-  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0, size_t = 0) {
+  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0, size_t = 0, int = 0) {
     auto t0 = std::chrono::steady_clock::now();
     f.run_serial(n);
     account(name, t0, alg_bytes);
@@ -248,11 +248,12 @@ struct Backend {
     launch_kernel(mas_kernel_2d<F, BY>, dim3((hi - lo + 63) / 64, (ny + BY - 1) / BY), dim3(64, BY), f, lo, hi, ny);
     end();
   }
+  // force_threads: workgroup size when it is not one lane per item (the body shares its loops out over the threads itself)
   template <class F>
-  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0, size_t lds_bytes = 0) {
+  void launch_group(const char* name, const F& f, int n, double alg_bytes = 0.0, size_t lds_bytes = 0, int force_threads = 0) {
     if (n <= 0) return;
     begin(name, alg_bytes);
-    const int threads = ((n + 63) / 64) * 64;
+    const int threads = force_threads > 0 ? force_threads : ((n + 63) / 64) * 64;
     if (threads <= 256) launch_kernel_lds(mas_kernel_group<F, 256>, dim3(1), dim3(threads), lds_bytes, f, n);
     else if (threads <= 512) launch_kernel_lds(mas_kernel_group<F, 512>, dim3(1), dim3(threads), lds_bytes, f, n);
     else launch_kernel_lds(mas_kernel_group<F, 1024>, dim3(1), dim3(threads), lds_bytes, f, n);

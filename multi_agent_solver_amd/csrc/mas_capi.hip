@@ -115,6 +115,7 @@ int mas_hip_run_sequential(mas_hip_solver* h, int max_outer) { return guarded(h,
 int mas_hip_run_trust_region(mas_hip_solver* h, int max_outer) { return guarded(h, [&](mas::SolverBase& s) { s.run_trust_region(max_outer); }); }
 int mas_hip_run_line_search(mas_hip_solver* h, int max_outer) { return guarded(h, [&](mas::SolverBase& s) { s.run_line_search(max_outer); }); }
 int mas_hip_run_centralized(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.run_centralized(); }); }
+int mas_hip_run_centralized_dense(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.run_centralized_dense(); }); }
 
 int mas_hip_get_solution_host(mas_hip_solver* h, double* X, double* U, double* cost, int32_t* iterations, int32_t* exit_status) {
   return guarded(h, [&](mas::SolverBase& s) { s.get_solution(X, U, cost, iterations, exit_status, false); });

@@ -19,6 +19,7 @@
 #include "mas_backend.hpp"
 #include "mas_bodies.hpp"
 #include "mas_central.hpp"
+#include "mas_dense.hpp"
 #if !defined(MAS_HOST_EMULATION)
 #include "mas_kernels_hip.hpp"
 #endif
@@ -52,6 +53,7 @@ class SolverBase {
   virtual void run_trust_region(int max_outer) = 0;
   virtual void run_line_search(int max_outer) = 0;
   virtual void run_centralized() = 0;
+  virtual void run_centralized_dense() = 0;
   virtual void get_solution(double* X, double* U, double* cost, int32_t* iters, int32_t* exit_code, bool device_ptr) = 0;
   virtual double total_cost() = 0;
   virtual void get_trust_radii(double* radii) = 0;
@@ -282,6 +284,30 @@ class SolverImpl final : public SolverBase {
     central_total = host_central->cur_total; last_total_valid = true;
     if (exit_reason == kExitConverged) stats.converged_solves += 1;
     fill_int(exit_code, exit_reason);
+  }
+
+  // centralized.hpp:18-38 in the reference's literal reading: ONE iLQR on the stacked OCP with finite differences of the
+  // summed cost (mas_dense.hpp).  Small problems only; one workgroup walks the whole solve.
+  void run_centralized_dense() override {
+    Timer tm(*this);
+    require(have_x0, "initial states not set");
+    if (d.N > kDenseMaxAgents) throw std::invalid_argument("the literal stacked solve is limited to " + std::to_string(kDenseMaxAgents) +
+                                                          " agents (4 (N nx)^2 evaluations of the N-agent cost per time step); use run_centralized");
+    be.zero(U, sizeof(double) * d.T * NU * d.Np);       // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109)
+    const size_t need = DenseCentralBody<M>::workspace_doubles(d.N, d.T);
+    if (!dense_ws || dense_ws_size < need) { dense_ws = dalloc(need); dense_ws_size = need; dense_flags = ialloc(16); }
+    DenseCentralBody<M> body;
+    body.d = d; body.dt = dt; body.P = P; body.clamp = clamp;
+    for (int i = 0; i < NU; ++i) { body.lb[i] = lb[i]; body.ub[i] = ub[i]; }
+    body.tolerance = tolerance; body.max_iterations = max_iterations; body.max_ms = max_ms;
+    body.x0 = x0; body.X = X; body.U = U; body.cost = cost; body.iters_total = iters_total; body.exit_code = exit_code; body.reg_events = reg_events;
+    body.st = central; body.ws = dense_ws; body.flags = dense_flags;
+    be.launch_group("central_dense", body, d.N, 0.0, 0, /*threads=*/256);
+    be.d2h(host_central, central, sizeof(CentralState));
+    central_total = host_central->cur_total; last_total_valid = true;
+    stats.solves += 1; stats.agent_iterations += static_cast<long long>(host_central->iterations) * d.N; stats.batch_iterations += host_central->iterations;
+    if (host_central->done) stats.converged_solves += 1;
+    initialized = false; rollout_consistent = false;     // cost[] now holds per-agent objectives of the stacked solution, merit[] is stale
   }
 
   void get_solution(double* Xo, double* Uo, double* co, int32_t* it, int32_t* ex, bool device_ptr) override {
@@ -690,6 +716,7 @@ class SolverImpl final : public SolverBase {
   double *x0 = nullptr, *X = nullptr, *U = nullptr, *D = nullptr, *kff = nullptr, *Kfb = nullptr, *Xs = nullptr, *Us = nullptr;
   double *trial_merit = nullptr, *cost = nullptr, *merit = nullptr, *x0_saved = nullptr, *U_saved = nullptr, *stage = nullptr;
   double *Dsoa = nullptr;
+  double *dense_ws = nullptr; size_t dense_ws_size = 0; int *dense_flags = nullptr;   // literal stacked solve (mas_dense.hpp)
   double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;

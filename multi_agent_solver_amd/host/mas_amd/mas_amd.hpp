@@ -425,14 +425,24 @@ inline void initialize_agents(MultiAgentProblem& problem) {
 }
 
 // ----------------------------------------------------------------------- strategies ------
-struct CentralizedStrategy {                       // strategies/centralized.hpp:10-39
+// strategies/centralized.hpp:10-39.  The reference stacks all agents into one OCP and finite-differences the SUMMED cost
+// (dense cross-agent Hessians): `Literal` is that solve on the device (mas_hip_run_centralized_dense, <= 16 agents -- it is
+// 4 (N nx)^2 evaluations of the N-agent cost per time step); `Blocked` is the block-diagonal reading that scales
+// (mas_hip_run_centralized, <= 1024 agents; a different number).  `Auto` takes the literal solve
+// where it exists, so that small problems -- the reference's own example defaults to 10 agents -- get the reference's number.
+struct CentralizedStrategy {
+  enum class Reading { Auto, Literal, Blocked };
+  static constexpr int kLiteralMaxAgents = 16;
   Solver solver;
-  explicit CentralizedStrategy(Solver s) : solver(std::move(s)) {}
+  Reading reading = Reading::Auto;
+  explicit CentralizedStrategy(Solver s, Reading r = Reading::Auto) : solver(std::move(s)), reading(r) {}
   Solution operator()(MultiAgentProblem& problem) {
     problem.compute_offsets();
     if (problem.blocks.empty()) return Solution{};
     auto bp = detail::upload(problem, detail::params_of(solver), false);
-    bp.batch->check(mas_hip_run_centralized(bp.batch->get()), "run_centralized");
+    const bool literal = reading == Reading::Literal || (reading == Reading::Auto && bp.N <= kLiteralMaxAgents);
+    if (literal) bp.batch->check(mas_hip_run_centralized_dense(bp.batch->get()), "run_centralized_dense");
+    else bp.batch->check(mas_hip_run_centralized(bp.batch->get()), "run_centralized");
     return detail::download(problem, bp, false);
   }
 };

@@ -131,14 +131,23 @@ def test_golden_fixtures_on_the_gpu(gpu_lib):
     spec.loader.exec_module(mov)
     gold = json.load(open(os.path.join(here, "golden", "oracle_vectors.json")))["cases"]
     for name, c in gold.items():
-        if c["strategy"] == "centralized_dense":
-            continue    # the literal stacked solve exists only in the oracle
-        x0, U0 = mov.inputs(c["model"], c["N"], c["T"], c["dt"])
+        x0, U0 = mov.inputs(c["model"], c["N"], c["T"], c["dt"])     # (centralized_dense: the literal stacked solve, mas_hip_run_centralized_dense)
         e = run_batch(gpu_lib, c["model"], x0, U0, c["T"], c["dt"], c["strategy"], max_outer=c["max_outer"],
                       max_iterations=c["max_iterations"], tolerance=c["tolerance"])
         assert [float.hex(v) for v in e["cost"]] == c["cost"], name
         assert e["iters"].tolist() == c["iters"], name
         assert [[float.hex(v) for v in e["X"][a, -1]] for a in range(c["N"])] == c["x_final"], name
+
+
+@pytest.mark.parametrize("N,T", [(2, 10), (4, 10), (10, 10), (16, 12), (3, 40)])
+def test_centralized_dense_literal_stacked_solve(gpu_lib, oracle, N, T):
+    """mas_hip_run_centralized_dense: the reference's LITERAL centralised strategy -- one iLQR on the stacked OCP, finite
+    differences of the summed cost, dense cross-agent Hessians, dense LLT and gains (centralized.hpp:18-38,
+    multi_agent_problem.hpp:52-127) -- bit-equal to the oracle's dense restatement up to its limit of 16 agents."""
+    x0 = oracle.single_track_x0(N)
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "centralized_dense")
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy="centralized_dense")
+    _same(e, o)
 
 
 def test_centralized_against_the_dense_stacked_goldens(gpu_lib):

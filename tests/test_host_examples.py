@@ -70,10 +70,28 @@ def test_single_track_example_matches_oracle(exe_dir, oracle, strategy):
     m = _result_line(r.stdout)
     canon = {"sequential_nash": "sequential", "Centralised": "centralized"}.get(strategy, strategy)
     assert m.group(1) == "ilqr" and m.group(2) == canon and m.group(3) == "6"
-    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(6), None, 10, 0.5, strategy=canon)
+    # 6 agents: the centralised strategy takes the reference's literal stacked solve (<= 16 agents), not the block-diagonal reading
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(6), None, 10, 0.5,
+                           strategy="centralized_dense" if canon == "centralized" else canon)
     assert m.group(4) == f"{o['total_cost']:.6f}"
     # trajectory tables: agent_<id>_states / _controls with time,x0.. header (example_utils.hpp:123-167)
     assert "agent_0_states\ntime,x0,x1,x2,x3\n" in r.stdout and "agent_5_controls\ntime,u0,u1\n" in r.stdout
+
+
+@pytest.mark.gpu
+def test_centralized_example_switches_reading_with_the_agent_count(exe_dir, oracle):
+    """reference default (10 agents, T = 10): the literal stacked solve; beyond 16 agents: the block-diagonal reading"""
+    r = _run(exe_dir, "multi_agent_single_track", "--quiet")
+    assert r.returncode == 0, r.stderr
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(10), None, 10, 0.5, strategy="centralized_dense")
+    assert _result_line(r.stdout).group(2) == "centralized" and _result_line(r.stdout).group(4) == f"{o['total_cost']:.6f}"
+    # (24, not 20: the example builds x0 with g++'s std::cos / std::sin like the reference's example does, the oracle's generator
+    #  with CPython's math module; for some agent counts -- 20, 30, 40 -- the two differ in the last bit of one coordinate, and
+    #  the algorithm turns that into 2e-5 of the total cost.  Inputs are outside the parity claim; equal inputs give equal bits.)
+    r = _run(exe_dir, "multi_agent_single_track", "--agents", "24", "--quiet")
+    assert r.returncode == 0, r.stderr
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(24), None, 10, 0.5, strategy="centralized")
+    assert abs(float(_result_line(r.stdout).group(4)) - o["total_cost"]) <= 1e-6      # printed with six decimals
 
 
 @pytest.mark.gpu

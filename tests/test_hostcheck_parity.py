@@ -214,3 +214,27 @@ def test_perturbed_agents_finish_their_solves_in_different_rounds(hostcheck_lib,
     o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, U0, T, 0.5, strategy=strategy, max_outer=outer)
     _same(e, o)
     assert len(set(o["iters"].tolist())) > 3
+
+
+@pytest.mark.parametrize("N,T", [(2, 10), (4, 10), (10, 10), (3, 25)])
+def test_centralized_dense_literal_stacked_solve(hostcheck_lib, oracle, N, T):
+    """mas_hip_run_centralized_dense: ONE iLQR on the stacked OCP with finite differences of the SUMMED cost
+    (centralized.hpp:18-38, multi_agent_problem.hpp:52-127) -- the reference's literal reading, dense cross-agent
+    Hessians and all.  Bit-equal to the oracle's dense restatement: per-agent costs, trajectories, iterations, total."""
+    x0 = oracle.single_track_x0(N)
+    e = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "centralized_dense")
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy="centralized_dense")
+    _same(e, o)
+    b = run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "centralized")
+    assert not np.array_equal(b["cost"], e["cost"])                      # the block-diagonal reading is a different number ...
+    assert abs(b["total_cost"] - e["total_cost"]) <= 2e-2 * e["total_cost"]   # ... close to it
+
+
+def test_centralized_dense_other_models_and_limits(hostcheck_lib, oracle):
+    x0 = oracle.lqr_x0(3)                                                 # stacked OCP: FD even where the agents have analytic hooks
+    e = run_batch(hostcheck_lib, oracle.MODEL_LQR_IDENTITY, x0, None, 12, 0.1, "centralized_dense")
+    o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0, None, 12, 0.1, strategy="centralized_dense")
+    _same(e, o)
+    from multi_agent_solver_amd._capi import MasHipError
+    with pytest.raises(MasHipError):                                      # 17 agents: beyond the literal solve's limit, loudly
+        run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(17), None, 5, 0.5, "centralized_dense")
