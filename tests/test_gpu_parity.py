@@ -358,3 +358,26 @@ def test_config5_bicycle6_shard_properties_and_full_parity(gpu_lib, oracle):
     assert np.array_equal(e["cost"], o["cost"]) and np.array_equal(e["X"], o["X"]) and np.array_equal(e["U"], o["U"])
     assert e["iters"].tolist() == o["iters"].tolist()
     assert e["status"].tolist() == o["status"].tolist()
+
+
+def test_maximum_sizes(gpu_lib, oracle):
+    """the limits the ABI states: 1024 agents for the block-diagonal centralised strategy (1025 is refused, loudly), 16 for
+    the literal one, and a 65536-agent batch (BASELINE configs[4]'s total on ONE device: 7 GB of 288) for the per-agent path"""
+    from multi_agent_solver_amd._capi import MasHipError
+    N, T = 1024, 12
+    x0 = oracle.single_track_x0(N)
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "centralized")
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy="centralized")
+    _same(e, o, total_exact=False)
+    with pytest.raises(MasHipError):
+        run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(1025), None, 5, 0.5, "centralized")
+    with pytest.raises(MasHipError):
+        run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(17), None, 5, 0.5, "centralized_dense")
+    N, T = 65536, 100
+    x0 = oracle.single_track_x0(N)
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "sequential", max_outer=2)
+    sample = np.arange(0, N, 37)                              # 1772 agents re-solved alone by the oracle (agents are independent)
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0[sample], None, T, 0.5, strategy="sequential", max_outer=2)
+    assert np.array_equal(e["cost"][sample], o["cost"]) and np.array_equal(e["X"][sample], o["X"]) and np.array_equal(e["U"][sample], o["U"])
+    assert e["iters"][sample].tolist() == o["iters"].tolist()
+    assert np.isfinite(e["cost"]).all() and (np.abs(e["U"]) <= 0.5).all() and e["stats"]["agent_iterations"] == int(e["iters"].sum())
