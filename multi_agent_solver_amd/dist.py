@@ -64,12 +64,16 @@ def all_gather_solution(solver, n_total: int, group=None, device=None):
     X = torch.zeros((width, solver.T + 1, solver.nx), dtype=torch.float64, device=device)
     U = torch.zeros((width, solver.T, solver.nu), dtype=torch.float64, device=device)
     cost = torch.zeros(width, dtype=torch.float64, device=device)
-    # stream-ordering contract of the *_device entry points (include/mas_hip.h): the handle works on its OWN stream, so the
-    # zero-fills torch just enqueued on its current stream must have finished before the solver writes into the buffers;
-    # on return from solution_device the results are complete (the call synchronises the handle's stream)
     if device.type == "cuda":
+        # stream-ordering contract of the *_device entry points (include/mas_hip.h): the handle works on its OWN stream, so the
+        # zero-fills torch just enqueued on its current stream must have finished before the solver writes into the buffers;
+        # on return from solution_device the results are complete (the call synchronises the handle's stream)
         torch.cuda.current_stream(device).synchronize()
-    solver.solution_device(X.data_ptr(), U.data_ptr(), cost.data_ptr())       # fills the first n_local agents
+        solver.solution_device(X.data_ptr(), U.data_ptr(), cost.data_ptr())       # fills the first n_local agents
+    else:
+        # host tensors (gloo): through the host entry point -- a device handle must never be handed a host pointer as a device one
+        sol = solver.solution()
+        X[:n_local] = torch.from_numpy(sol["X"]); U[:n_local] = torch.from_numpy(sol["U"]); cost[:n_local] = torch.from_numpy(sol["cost"])
     out = {}
     for name, mine in (("X", X), ("U", U), ("cost", cost)):
         parts = [torch.empty_like(mine) for _ in range(world)]
