@@ -30,6 +30,22 @@ struct CentralState {
   int pad;
 };
 
+#if !defined(MAS_HOST_EMULATION)
+// sum of v[0..n-1] in index order from 0.0 -- the serial loop's rounding -- by ONE wavefront: 64 values per coalesced load,
+// then added up lane by lane through v_readlane (a thread walking the array alone pays a full memory round trip per value).
+// Lanes beyond n contribute -0.0, which changes no bit of the running sum.  Every lane returns the sum.
+__device__ inline double wave_serial_sum(const double* v, int n) {
+  const int lane = static_cast<int>(threadIdx.x) & 63;
+  double s = 0.0;
+  for (int base = 0; base < n; base += 64) {
+    const int a = base + lane;
+    const double x = a < n ? v[a] : -0.0;
+    MAS_UNROLL for (int i = 0; i < 64; ++i) s += __shfl(x, i);
+  }
+  return s;
+}
+#endif
+
 // serial sum in agent order (the stacked objective adds the blocks in block order)
 struct CentralInitBody {
   Dims d; const double* cost; CentralState* st;
@@ -40,9 +56,9 @@ struct CentralInitBody {
   }
 #else
   __device__ void run_block(int n) const {
-    if (threadIdx.x == 0) {
-      double s = 0.0; for (int a = 0; a < n; ++a) s += cost[a];
-      st->cur_total = s; st->improvement = 0.0; st->j_sel = -1; st->done = 0; st->iterations = 0;
+    if (threadIdx.x < 64) {
+      const double s = wave_serial_sum(cost, n);
+      if (threadIdx.x == 0) { st->cur_total = s; st->improvement = 0.0; st->j_sel = -1; st->done = 0; st->iterations = 0; }
     }
   }
 #endif
@@ -168,7 +184,11 @@ struct CentralSelectBody {
     __shared__ double sums[kNumAlphas];
     __shared__ int sel_sh;
     const int tid = threadIdx.x;
-    if (tid < kNumAlphas) { double s = 0.0; for (int a = 0; a < n; ++a) s += trial_merit[static_cast<size_t>(tid) * d.Np + a]; sums[tid] = s; }
+    const int wave = tid >> 6, n_waves = (static_cast<int>(blockDim.x) + 63) >> 6;
+    for (int j = wave; j < kNumAlphas; j += n_waves) {                  // one wavefront per alpha trial (several trials per wavefront if the block is small)
+      const double s = wave_serial_sum(trial_merit + static_cast<size_t>(j) * d.Np, n);
+      if ((tid & 63) == 0) sums[j] = s;
+    }
     __syncthreads();
     if (tid == 0) { decide(sums, tolerance, st); sel_sh = st->j_sel; }
     __syncthreads();
