@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(64) mas_kernel_1d(const F f, int lo, int hi) {
 template <class F, int BY>
 __global__ void __launch_bounds__(64 * BY) mas_kernel_2d(const F f, int lo, int hi, int ny) {
   const int a = lo + blockIdx.x * 64 + threadIdx.x;
-  int y = blockIdx.y;                                    // BY == 1: wave-uniform, so everything indexed by y stays scalar
-  if constexpr (BY > 1) y = blockIdx.y * BY + threadIdx.y;
+  int y = blockIdx.y;                                    // wave-uniform (a wavefront is one row of the block): kept scalar
+  if constexpr (BY > 1) y = blockIdx.y * BY + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   if (a < hi && y < ny) f(a, y);
 }
 // one workgroup whose lanes cooperate through barriers (centralised strategy); MAXT bounds the

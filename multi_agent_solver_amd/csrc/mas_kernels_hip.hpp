@@ -232,10 +232,14 @@ __device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned
   return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(agreed)));
 }
 
-// WPB = wavefronts per workgroup.  1 for the per-agent Nash path.  The shared ladder of the centralised strategy runs WPB > 1:
-// the rung masks of a workgroup's wavefronts are first combined through LDS (one s_barrier), and only ONE wavefront per
-// workgroup takes part in the cross-workgroup agreement, so 256 agents are 4-16 arrivals per time step instead of 64 --
-// and a problem that fits one workgroup needs no global agreement at all.
+// WPB = wavefronts per workgroup; the wavefronts of a workgroup are independent (each owns its four LDS tiles) except in the
+// shared ladder.  Two reasons for WPB = 4:
+//  * placement (per-agent Nash path): a workgroup's four wavefronts go to the four SIMDs of one CU, so 4096 agents = 256
+//    workgroups = exactly one wavefront per SIMD.  As 1024 single-wavefront workgroups the dispatcher doubles some SIMDs up
+//    while others stay empty, and the launch takes as long as its slowest SIMD: measured 163 us against 124 us per launch.
+//  * the shared ladder of the centralised strategy: the rung masks of a workgroup's wavefronts are first combined through
+//    LDS (one s_barrier), and only ONE wavefront per workgroup takes part in the cross-workgroup agreement, so 256 agents
+//    are 16 arrivals per time step instead of 64 -- and a problem that fits one workgroup needs no global agreement at all.
 template <class M, int LPA, bool SharedLadder = false, int WPB = 1>
 __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
                                                                double* __restrict__ kff, double* __restrict__ Kfb,
@@ -256,7 +260,6 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
 #else
   constexpr bool kLocalQuu = false;
 #endif
-  static_assert(WPB == 1 || SharedLadder, "several wavefronts per workgroup only for the shared ladder");
   __shared__ double lds[WPB * APW * TL::STRIDE];
   __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];   // rung masks of the workgroup's wavefronts, double-buffered by agreement parity
   __shared__ unsigned blk_agreed[2];

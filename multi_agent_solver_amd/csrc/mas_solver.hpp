@@ -484,7 +484,9 @@ class SolverImpl final : public SolverBase {
     }
     be.begin("backward", bytes);
     constexpr int apw = 64 / kBackwardLanesPerAgent;
-    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false>, dim3((hi - lo + apw - 1) / apw), dim3(64), d, P, X, D, kff, Kfb, reg_events, active, lo, hi, LadderSync{});
+    constexpr int wpb = kBackwardWavesPerBlock;       // four wavefronts per workgroup: one per SIMD of a CU (mas_kernels_hip.hpp)
+    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false, wpb>, dim3((hi - lo + wpb * apw - 1) / (wpb * apw)), dim3(64 * wpb), d, P, X, D, kff, Kfb,
+                     reg_events, active, lo, hi, LadderSync{});
     be.end();
 #endif
   }
@@ -606,7 +608,7 @@ class SolverImpl final : public SolverBase {
       // more than its few live workgroups do
       launch_sweep(sweep_bytes(), 0, d.N, live, live ? static_cast<int>(live_upper) : d.N);
       launch_backward(backward_bytes(), 0, d.N);
-      be.template launch_2d_range<1>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
+      be.template launch_2d_range<kForwardTrialsPerBlock>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
       const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
