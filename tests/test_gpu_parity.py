@@ -314,6 +314,34 @@ def test_torch_tensors_without_a_manual_synchronize(gpu_lib, oracle):
     assert np.array_equal(host["cost"], o["cost"])
 
 
+def test_handle_on_the_callers_stream(gpu_lib, oracle):
+    """mas_hip_create_on_stream: the handle works on torch's current stream, so its copies are ordered with the tensors'
+    producers and consumers by the stream itself -- the other way to satisfy the *_device contract (include/mas_hip.h)"""
+    import torch
+    from multi_agent_solver_amd.batch import BatchSolver
+    N, T = 256, 20
+    x0 = oracle.single_track_x0(N)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        x0_t = torch.from_numpy(x0).to(dev, non_blocking=True) + 0.0
+        U_t = torch.zeros((N, T, 2), dtype=torch.float64, device=dev)
+        with BatchSolver(oracle.MODEL_SINGLE_TRACK, N, T, 0.5, lib=gpu_lib, stream=stream.cuda_stream) as s:
+            s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+            s.set_initial_states_device(x0_t.data_ptr())
+            s.set_controls_device(U_t.data_ptr())
+            s.initialize_problem()
+            s.run_trust_region(2)
+            X_out = torch.zeros((N, T + 1, 4), dtype=torch.float64, device=dev)
+            c_out = torch.zeros((N,), dtype=torch.float64, device=dev)
+            s.solution_device(X_out.data_ptr(), 0, c_out.data_ptr())
+            total = (c_out.sum() * 1.0).item()
+            host = s.solution()
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy="trustregion", max_outer=2)
+    assert np.array_equal(X_out.cpu().numpy(), o["X"]) and np.array_equal(c_out.cpu().numpy(), o["cost"]) and np.array_equal(host["U"], o["U"])
+    assert abs(total - o["cost"].sum()) <= 1e-9 * o["cost"].sum()
+
+
 def test_centralized_single_workgroup_fallback(gpu_lib, oracle, monkeypatch):
     """when the workgroups of the rung-agreement kernel cannot all be resident (occupancy check), the
     centralised backward pass falls back to the single-workgroup kernel -- same results, bit for bit."""
