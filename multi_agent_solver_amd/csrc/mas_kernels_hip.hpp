@@ -35,7 +35,7 @@ namespace mas {
 // 64 slots hold one aligned block of 64 consecutive agents (every wavefront while all agents are active) keeps
 // the contiguous full-line store path; any other wavefront scatters whole tile chunks (128 B per agent and chunk).
 template <class M>
-__global__ void __launch_bounds__(256) mas_sweep_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ U,
+__global__ void __launch_bounds__(256, 2) mas_sweep_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ U,
                                                         double* __restrict__ D, const int* __restrict__ active, int lo, int n,
                                                         unsigned long long* __restrict__ stamp,
                                                         const int* __restrict__ live_list, const int* __restrict__ live_count) {
