@@ -317,10 +317,9 @@ struct SelectBody {
     if (!active[a]) { alpha_sel[a] = -1; if (dbg_iter) dbg_iter[a] = 0; return kIdle; }
     const double cur = merit[a];
     int sel = -1; double best = cur;
-    for (int j = 0; j < kNumAlphas; ++j) {
-      const double m = trial_merit[static_cast<size_t>(j) * d.Np + a];
-      if (m < best) { best = m; sel = j; break; }          // first strict decrease, ilqr.hpp:220-226
-    }
+    double tm[kNumAlphas];                                  // all ten loads in flight at once: a load per loop trip would put up to ten
+    MAS_UNROLL for (int j = 0; j < kNumAlphas; ++j) tm[j] = trial_merit[static_cast<size_t>(j) * d.Np + a];   // memory round trips on this kernel's critical path
+    MAS_UNROLL for (int j = kNumAlphas - 1; j >= 0; --j) { if (tm[j] < cur) { best = tm[j]; sel = j; } }      // FIRST strict decrease (ilqr.hpp:220-226) = the lowest such j
     const double improvement = cur - best;                  // 0 when no trial was accepted
     alpha_sel[a] = sel;
     if (sel >= 0) { cost[a] = trial_obj ? trial_obj[static_cast<size_t>(sel) * d.Np + a] : best; merit[a] = best; }   // cost = objective(best_x,best_u); current_merit = best_merit
