@@ -302,7 +302,7 @@ class SolverImpl final : public SolverBase {
     body.tolerance = tolerance; body.max_iterations = max_iterations; body.max_ms = max_ms;
     body.x0 = x0; body.X = X; body.U = U; body.cost = cost; body.iters_total = iters_total; body.exit_code = exit_code; body.reg_events = reg_events;
     body.st = central; body.ws = dense_ws; body.flags = dense_flags;
-    be.launch_group("central_dense", body, d.N, 0.0, 0, /*threads=*/256);
+    be.launch_group("central_dense", body, d.N, 0.0, 0, /*threads=*/1024);
     be.d2h(host_central, central, sizeof(CentralState));
     central_total = host_central->cur_total; last_total_valid = true;
     stats.solves += 1; stats.agent_iterations += static_cast<long long>(host_central->iterations) * d.N; stats.batch_iterations += host_central->iterations;
