@@ -117,6 +117,18 @@ def test_lqr_and_pendulum_examples(exe_dir, oracle):
 
 
 @pytest.mark.gpu
+def test_single_track_ocp_example(exe_dir, oracle):
+    """examples/single_track_ocp.cpp: lane following, analytic derivatives, max_iterations 10; result line + `single_track_*` tables"""
+    r = _run(exe_dir, "single_track_ocp")
+    assert r.returncode == 0, r.stderr
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK_LANE, np.array([[0.0, 1.0, 0.0, 0.0]]), None, 80, 0.1, strategy="single", max_iterations=10)
+    assert _result_line(r.stdout).group(1) == "ilqr" and _result_line(r.stdout).group(4) == f"{o['cost'][0]:.6f}" == "508.593060"
+    assert "single_track_states\ntime,x0,x1,x2,x3\n" in r.stdout and "single_track_controls\ntime,u0,u1\n" in r.stdout
+    h = _run(exe_dir, "single_track_ocp", "--help")
+    assert h.returncode == 0 and h.stdout.startswith("Usage: single_track_ocp [--solver NAME]")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("strategy", ["sequential", "trustregion"])
 def test_mixed_models_are_split_into_homogeneous_batches(exe_dir, oracle, strategy):
     """agents of different models in one MultiAgentProblem (allowed by the reference: every agent owns its OCP)"""
