@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 from multi_agent_solver_amd.batch import BatchSolver  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
+BIG = int(os.environ.get("FUZZ_BIG", "1"))      # agent-count multiplier (FUZZ_BIG=8: batches of thousands, slower oracle)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
@@ -25,12 +26,12 @@ for c in range(cases):
     model = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 6]))
     nx, nu, _ = O.model_dims(model)
     strategy = str(rng.choice(["single", "sequential", "trustregion", "linesearch", "centralized", "centralized_dense"]))
-    N = int(rng.integers(1, 700)) if model in (1, 2, 6) else int(rng.integers(1, 80))
+    N = int(rng.integers(1, 700 * BIG)) if model in (1, 2, 6) else int(rng.integers(1, 80 * BIG))
     T = int(rng.integers(1, 60))
     if model == 3:
         N, T = int(rng.integers(1, 4)), int(rng.integers(5, 40))
     if strategy == "centralized":
-        N = min(N, 200)
+        N = min(N, 200 * min(BIG, 5))
     if strategy == "centralized_dense":
         N, T = int(rng.integers(1, 7)), int(rng.integers(1, 9))
     if model == 5:
