@@ -387,6 +387,27 @@ struct CommitBody {
   }
 };
 
+// the same copy after a four-lanes-per-rollout line search (mas_forward_quad_kernel): its trial planes are indexed by the
+// SLOT of the agent in the round's list of live agents (null list: slot == agent)
+template <class M>
+struct CommitSlotBody {
+  Dims d;
+  const double* Xs; const double* Us; const int* alpha_sel;
+  double* X; double* U;
+  const int* live_list; const int* live_count;
+  MAS_HD void operator()(int slot, int t) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (live_count && slot >= *live_count) return;
+    const int a = live_list ? live_list[slot] : slot;
+    const int j = alpha_sel[a];
+    if (j < 0) return;
+    const double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
+    const double* Uj = Us + static_cast<size_t>(j) * d.T * NU * d.Np;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(X, t * NX + i, a) = MAS_AT(Xj, t * NX + i, slot);
+    if (t < d.T) { MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(U, t * NU + i, a) = MAS_AT(Uj, t * NU + i, slot); }
+  }
+};
+
 // multiplier / penalty update and termination for constrained models, ilqr.hpp:236-260,269-271 (after commit)
 template <class M>
 struct ALUpdateBody {

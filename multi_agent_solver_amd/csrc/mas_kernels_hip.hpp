@@ -23,6 +23,7 @@
 #pragma once
 
 #include <type_traits>
+#include <utility>
 
 #include "mas_bodies.hpp"
 
@@ -149,6 +150,138 @@ __global__ void __launch_bounds__(256, 2) mas_sweep_kernel(Dims d, ModelParams P
       }
     }
   }
+}
+
+// ------------------------------------------------------- line-search rollouts, 4 lanes/trial --
+// ForwardBody gives every (agent, alpha) rollout one lane, and a lone wavefront issues one FP64 instruction every
+// four cycles: 4096 agents x 10 trials are 640 wavefronts whose 100-step chains of ~490 instructions ARE the launch
+// time, however few agents are still active.  This kernel spends FOUR lanes on a rollout -- one per RK4 stage -- for
+// the rounds (and problems) in which the live rollouts no longer fill the chip: the four sin/cos evaluations of a
+// step, ~45 % of its instructions, run side by side.  That is possible where the stage ARGUMENTS of the expensive part
+// do not depend on its results (QuadRk4 below: in the single-track model psi and v advance without sin/cos).
+//   lane (slot, s): slot = position in the compacted list of live agents, s = RK4 stage 0..3
+//   - control i = s & 1 of the feedback law on this lane, the pair exchanged inside the quad (DPP quad_perm)
+//   - every lane keeps the whole state (tan, cost and the final combination are evaluated redundantly: SIMD)
+//   - trial planes are indexed by SLOT, not by agent: the 16 slots of a wavefront are 16 consecutive doubles of a row,
+//     lane s stores state component s, so a store instruction writes four whole 128-byte lines (ForwardBody's
+//     whole-line rule); CommitSlotBody maps slot -> agent when it copies the accepted trial
+// Every arithmetic operation is the one rk4_step / forward_control / stage_cost perform for that rollout, on the same
+// operands in the same order -- only the lane that executes it changes -- so results are bit-identical to ForwardBody.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {      // quad_perm:[CTRL & 3, (CTRL >> 2) & 3, ...] on both halves
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) { return quad_perm<SRC * 0x55>(v); }      // every lane of the quad reads lane SRC
+__device__ __forceinline__ double quad_from_prev(double v) { return quad_perm<0x90>(v); }        // lane s reads lane s-1 (lane 0 itself)
+
+// integrate_rk4 (integrator.hpp:19-28) with lane s of a quad evaluating stage s.  Specialised per dynamics.
+template <class M> struct QuadRk4;
+// single-track (examples/models/single_track_model.hpp:23-44): d(psi)/dt = v tan(delta) / L and dv/dt = a do not
+// involve X, Y, sin or cos, so lane s forms ITS stage's v and psi from x, u alone (one psi-rate from the lane below),
+// evaluates sin/cos there, and the quad exchanges the four stages' X- and Y-rates.
+template <>
+struct QuadRk4<SingleTrack> {
+  __device__ static void step(const double* x, const double* u, double dt, int s, double* out, const ModelParams& P) {
+    const SingleTrack::Ctl c = SingleTrack::prepare(u, P);
+    const double a = u[1], L = P.p[6];
+    const double h = (s == 3) ? dt : (0.5 * dt);                       // x + (0.5*dt)*k1, x + (0.5*dt)*k2, x + dt*k3
+    const double hv = x[3] + h * a;
+    const double vs = (s == 0) ? x[3] : hv;                             // stage 0 evaluates f at x itself
+    const double kpsi = vs * c.tan_delta / L;                          // dynamics_c: d[2]
+    const double hp = x[2] + h * quad_from_prev(kpsi);
+    const double psis = (s == 0) ? x[2] : hp;
+    double sn, cs;
+    mas_dt_sincos(psis, &sn, &cs);
+    const double kx = vs * cs, ky = vs * sn;                            // d[0], d[1]
+    const double k1x = quad_bcast<0>(kx), k2x = quad_bcast<1>(kx), k3x = quad_bcast<2>(kx), k4x = quad_bcast<3>(kx);
+    const double k1y = quad_bcast<0>(ky), k2y = quad_bcast<1>(ky), k3y = quad_bcast<2>(ky), k4y = quad_bcast<3>(ky);
+    const double k1p = quad_bcast<0>(kpsi), k2p = quad_bcast<1>(kpsi), k3p = quad_bcast<2>(kpsi), k4p = quad_bcast<3>(kpsi);
+    out[0] = x[0] + (dt / 6.0) * (((k1x + 2.0 * k2x) + 2.0 * k3x) + k4x);
+    out[1] = x[1] + (dt / 6.0) * (((k1y + 2.0 * k2y) + 2.0 * k3y) + k4y);
+    out[2] = x[2] + (dt / 6.0) * (((k1p + 2.0 * k2p) + 2.0 * k3p) + k4p);
+    out[3] = x[3] + (dt / 6.0) * (((a + 2.0 * a) + 2.0 * a) + a);
+  }
+};
+template <> struct QuadRk4<SingleTrackLane> : QuadRk4<SingleTrack> {};
+
+template <class M>
+__global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody<M> f, const int* __restrict__ live_list, const int* __restrict__ live_count) {
+  constexpr int NX = M::NX, NU = M::NU;
+  static_assert(NX == 4 && NU == 2, "one state component per lane of the quad, one control per lane pair");
+  const Dims d = f.d;
+  const int tid = static_cast<int>(threadIdx.x), s = tid & 3, ci = s & 1;
+  const int n_live = live_count ? *live_count : d.N;                   // uniform
+  const int slot0 = (static_cast<int>(blockIdx.x) * 64 + (tid >> 6) * 16);
+  if (slot0 >= n_live) return;                                         // wave-uniform
+  const int slot = slot0 + ((tid & 63) >> 2);
+  // a surplus quad of the last wavefront repeats the wavefront's first rollout (finite operands, in-range addresses); it
+  // stores into its own, unused slot columns, and its merit is not stored
+  const bool act = slot < n_live;
+  const int src = act ? slot : slot0;
+  const int a = live_list ? live_list[src] : src;
+  const int j = static_cast<int>(blockIdx.y);
+  double alpha = 1.0;
+  for (int q = 0; q < j; ++q) alpha *= 0.5;
+  double* Xj = f.Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
+  double* Uj = f.Us + static_cast<size_t>(j) * d.T * NU * d.Np;
+
+  // loads: uniform per-step base pointers + loop-invariant 32-bit byte offsets (row_in_step * Np + agent) * 8
+  unsigned offx[NX], offu, offK[NX];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) offx[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  offu = static_cast<unsigned>((static_cast<size_t>(ci) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int c = 0; c < NX; ++c) offK[c] = static_cast<unsigned>((static_cast<size_t>(c * NU + ci) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  // stores: lane s owns state row s and control row s & 1 of its slot column
+  const unsigned sto_x = static_cast<unsigned>((static_cast<size_t>(s) * d.Np + static_cast<size_t>(slot)) * sizeof(double));
+  const unsigned sto_u = static_cast<unsigned>((static_cast<size_t>(ci) * d.Np + static_cast<size_t>(slot)) * sizeof(double));
+  const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np, sK = static_cast<size_t>(NU) * NX * d.Np;
+  const double *Xt = f.X, *Ut = f.U, *kt = f.kff, *Kt = f.Kfb;
+  double *Xjt = Xj, *Ujt = Uj;
+  struct Operands { double xr[NX], ur, k, K[NX]; };
+  Operands opA, opB;
+  auto request = [&](Operands& o) {
+    MAS_UNROLL for (int i = 0; i < NX; ++i) o.xr[i] = ld_off(Xt, offx[i]);
+    o.ur = ld_off(Ut, offu);
+    o.k = ld_off(kt, offu);
+    MAS_UNROLL for (int c = 0; c < NX; ++c) o.K[c] = ld_off(Kt, offK[c]);
+  };
+  double x[NX], xn[NX], u[NU];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = ld_off(f.x0, offx[i]);
+  auto own = [&](const double* v) { const double lo2 = (s & 1) ? v[1] : v[0], hi2 = (s & 1) ? v[3] : v[2]; return (s & 2) ? hi2 : lo2; };
+  st_off(Xjt, sto_x, own(x));
+  request(opA);
+  double lbv = f.lb[ci], ubv = f.ub[ci];
+  MAS_VGPR64(lbv); MAS_VGPR64(ubv);
+  double c = 0.0;
+  auto step = [&](int t, const Operands& cur, Operands& next) {
+    if (t + 1 < d.T) { Xt += sX; Ut += sU; kt += sU; Kt += sK; }     // uniform
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { MAS_OPAQUE32(offx[i]); MAS_OPAQUE32(offK[i]); }
+    MAS_OPAQUE32(offu);
+    request(next);
+    // forward_control (mas_lane.hpp), control ci on this lane
+    double ui;
+    {
+      double kd = 0.0;
+      MAS_UNROLL for (int q = 0; q < NX; ++q) kd += cur.K[q] * (x[q] - cur.xr[q]);
+      ui = (cur.ur + alpha * cur.k) + kd;
+      if (f.clamp) { ui = (ubv < ui) ? ubv : ui; ui = (ui < lbv) ? lbv : ui; }
+    }
+    u[0] = quad_bcast<0>(ui); u[1] = quad_bcast<1>(ui);
+    { unsigned o = sto_u; MAS_OPAQUE32(o); st_off(Ujt, o, ui); }
+    c += M::stage_cost(x, u, t, f.P);
+    QuadRk4<M>::step(x, u, f.dt, s, xn, f.P);
+    Xjt += sX; Ujt += sU;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xjt, o, own(x)); }
+  };
+  int t = 0;
+  for (; t + 1 < d.T; t += 2) { step(t, opA, opB); step(t + 1, opB, opA); }
+  if (t < d.T) step(t, opA, opB);
+  c += M::terminal_cost(x, f.P);
+  if (act && s == 0) f.trial_merit[static_cast<size_t>(j) * d.Np + a] = c;
 }
 
 // ---------------------------------------------------------------- backward, 16 lanes/agent --
@@ -333,7 +466,8 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     publish_at[c] = tile * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
   }
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
-  const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(a0 / 64)) * 64 * ND;
+  // (the 64-agent block of a wavefront is uniform: said explicitly, so that the base pointer lives in scalar registers)
+  const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(a0 / 64))) * 64 * ND;
   auto fetch = [&]() { MAS_UNROLL for (int c = 0; c < NCH; ++c) pre[c] = ld_off(tiles_t, fetch_off[c]); };
   long long regs = 0;
   // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
@@ -562,6 +696,290 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   };
   step(d.T - 1);
   for (int t = d.T - 2; t >= 0; --t) step(t);
+  if (valid && lane == 0) reg_events[a] += regs;
+}
+
+// ------------------------------------------------ backward, 16 lanes/agent, NX == 4: registers + DPP --
+// The tile kernel above exchanges everything through LDS: four write -> wait -> read round trips per time step, ~40 % of a
+// lone wavefront's step (SQ_WAIT_INST_LDS), and with four wavefronts per CU the LDS pipe itself is half busy.  For NX == 4
+// the 16 lanes of an agent are exactly one DPP row holding the 4 x 4 value Hessian, lane (i, j) = i + 4 j owning V(i, j):
+//   * V never touches LDS: column j of V is the lane's own quad (quad_perm broadcasts), v_x(k) lives in lane k of the row
+//     (v_mov_b64_dpp row_newbcast: one instruction hands lane n of a row to all 16 lanes);
+//   * the derivative tile never touches LDS either: every lane loads the two columns of A and B and the five scalars ITS
+//     items need straight from HBM / L2 into registers, one step ahead (the 16 lanes of an agent hit the same 464-byte tile);
+//   * q_uu and q_u reach all lanes by row_newbcast, so the LLT / ladder chain starts right after pass 2 without an LDS
+//     round trip, and the pass-2 results that do cross quads (q_ux columns, the mirror entry of q_xx) travel through LDS in
+//     the shadow of that chain.
+// Two LDS round trips are left on the chain of a step: the rows of A^T V / B^T V (a transposition across quads, which no DPP
+// row operation expresses) and the factor of the winning rung.  Item -> lane assignment (all items of a lane use ITS i, j):
+//   pass 1   (A^T V)(i,j), (B^T V)(i,j) [i < NU], q_x(i), q_u(i) [i < NU]
+//   pass 2   q_xx(i,j), q_ux(i,j) [i < NU], q_uu(i,j) [i, j < NU]
+//   pass 3   as in the tile kernel
+// Every output element is the same sequence of multiplies and adds as in the tile kernel and in BackwardBody.
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double2 ld2_off(const double* base, unsigned byte_off) { return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + byte_off); }
+// out[e] = the value lane (e % NU, e / NU) of the row holds, e < NU * NU (q_uu); out[m] = lane m's (q_u); out[m] = lane m of the quad's (q_ux column)
+template <int NU, int... E>
+__device__ __forceinline__ void row_gather_block(double v, double* out, std::integer_sequence<int, E...>) { ((out[E] = row_bcast<(E % NU) + 4 * (E / NU)>(v)), ...); }
+template <int... E>
+__device__ __forceinline__ void row_gather_first(double v, double* out, std::integer_sequence<int, E...>) { ((out[E] = row_bcast<E>(v)), ...); }
+template <int... E>
+__device__ __forceinline__ void quad_gather(double v, double* out, std::integer_sequence<int, E...>) { ((out[E] = quad_bcast<E>(v)), ...); }
+
+template <class M, bool SharedLadder = false, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
+                                                              double* __restrict__ kff, double* __restrict__ Kfb,
+                                                              long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n,
+                                                              LadderSync sync) {
+  using L = DerivLayout<M>;
+  constexpr int NX = 4, NU = M::NU, ND = L::ND;
+  static_assert(M::NX == 4 && NU >= 1 && NU <= 4, "one DPP row = the 4 x 4 value Hessian");
+  static_assert(L::oB + NX * NU <= 2 * kTileChunk && ND >= 2 * kTileChunk, "the columns of A and B lie in full-width chunks (16-byte aligned pairs)");
+  constexpr int LPA = 16, APW = 4, LL = 16;
+  // LDS per agent (doubles): rows of A^T V [i*4 + k], rows of B^T V [m*4 + k], q_xx [i + 4 j], q_ux columns [j*NU + m], the
+  // winning factor, 16 pad slots for lanes without an item (own slot per lane: no write conflicts); stride = 16 (mod 32)
+  constexpr int oAtV = 0, oBtV = 16, oQxx = 32, oQux = 48, oL = 64, oPad = 80, STRIDE = 112;
+  __shared__ double lds[WPB * APW * STRIDE];
+  __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];
+  __shared__ unsigned blk_agreed[2];
+  unsigned agreement_parity = 0;
+
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane;
+  const int i = lane & 3, j = lane >> 2, iu = (i < NU) ? i : NU - 1, ju = (j < NU) ? j : NU - 1;
+  const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
+  const bool valid = (a < n) && active[a] != 0;
+  if (!SharedLadder && __ballot(valid) == 0ull) return;
+  double* T = lds + (wave * APW + slot) * STRIDE;
+  auto wave_sync = [] {
+    if constexpr (WPB == 1) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // terminal boundary condition, ilqr.hpp:92-102: lane 0 evaluates it, every lane picks up its own entries
+  if (lane == 0) {
+    double xT[NX], vx[NX], vxx[NX * NX];
+    MAS_UNROLL for (int q = 0; q < NX; ++q) xT[q] = MAS_AT(X, d.T * NX + q, a);
+    terminal_boundary<M>(xT, vx, vxx, P);
+    MAS_UNROLL for (int q = 0; q < NX; ++q) T[oAtV + q] = vx[q];
+    MAS_UNROLL for (int q = 0; q < NX * NX; ++q) T[oQxx + q] = vxx[q];
+  }
+  wave_sync();
+  double Vown = T[oQxx + lane], vxi = T[oAtV + i];
+  wave_sync();
+
+  // this lane's operands of one tile: loop-invariant 32-bit byte offsets under a uniform base that steps back one time step
+  auto elem_off = [&](int e) {
+    const int c = e / kTileChunk, cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
+    return static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + static_cast<size_t>(e % kTileChunk)) * sizeof(double));
+  };
+  unsigned oAi = elem_off(L::oA + 4 * i), oAj = elem_off(L::oA + 4 * j), oBi = elem_off(L::oB + 4 * iu), oBj = elem_off(L::oB + 4 * ju);
+  unsigned olx = elem_off(L::oLx + i), olu = elem_off(L::oLu + iu), olxx = elem_off(L::oLxx + lane), olux = elem_off(L::oLux + iu + NU * j),
+           oluu = elem_off(L::oLuu + iu + NU * ju);
+  struct Tile { double2 Ai[2], Aj[2], Bi[2], Bj[2]; double lx, lu, lxx, lux, luu; };
+  const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
+  // (the 64-agent block of a wavefront is uniform: said explicitly, so that the base pointer lives in scalar registers)
+  const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(a0 / 64))) * 64 * ND;
+  auto fetch = [&](Tile& o) {
+    o.Ai[0] = ld2_off(tiles_t, oAi); o.Ai[1] = ld2_off(tiles_t, oAi + 16);
+    o.Aj[0] = ld2_off(tiles_t, oAj); o.Aj[1] = ld2_off(tiles_t, oAj + 16);
+    o.Bi[0] = ld2_off(tiles_t, oBi); o.Bi[1] = ld2_off(tiles_t, oBi + 16);
+    o.Bj[0] = ld2_off(tiles_t, oBj); o.Bj[1] = ld2_off(tiles_t, oBj + 16);
+    o.lx = ld_off(tiles_t, olx); o.lu = ld_off(tiles_t, olu); o.lxx = ld_off(tiles_t, olxx); o.lux = ld_off(tiles_t, olux); o.luu = ld_off(tiles_t, oluu);
+  };
+  long long regs = 0;
+  double rung_add[LL - 1];
+  {
+    double reg = 1e-6;
+    MAS_UNROLL for (int q = 0; q < LL - 1; ++q) { rung_add[q] = (q < rung_lane) ? reg : -0.0; reg *= 10.0; }
+  }
+  unsigned goff[NU], koff[NU];
+  MAS_UNROLL for (int m = 0; m < NU; ++m) goff[m] = static_cast<unsigned>((static_cast<size_t>(m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int m = 0; m < NU; ++m) koff[m] = static_cast<unsigned>((static_cast<size_t>(i * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  double* kff_t = kff + static_cast<size_t>(d.T - 1) * NU * d.Np;
+  double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
+  // LDS addresses of this lane (a lane without an item writes its own pad slot)
+  const int w_atv = oAtV + i * 4 + j, w_btv = (i < NU) ? (oBtV + i * 4 + j) : (oPad + lane);
+  const int w_qux = (i < NU) ? (oQux + j * NU + i) : (oPad + lane);
+
+  Tile tA, tB;
+  fetch(tA);
+  auto step = [&](int t, const Tile& c, Tile& nx) {
+    if (t > 0) tiles_t -= step_doubles;              // uniform; at t == 0 the (unused) prefetch re-reads step 0
+    MAS_OPAQUE32(oAi); MAS_OPAQUE32(oAj); MAS_OPAQUE32(oBi); MAS_OPAQUE32(oBj);
+    MAS_OPAQUE32(olx); MAS_OPAQUE32(olu); MAS_OPAQUE32(olxx); MAS_OPAQUE32(olux); MAS_OPAQUE32(oluu);
+    MAS_UNROLL for (int m = 0; m < NU; ++m) { MAS_OPAQUE32(goff[m]); MAS_OPAQUE32(koff[m]); }
+    fetch(nx);
+    const double Ai[NX] = {c.Ai[0].x, c.Ai[0].y, c.Ai[1].x, c.Ai[1].y}, Aj[NX] = {c.Aj[0].x, c.Aj[0].y, c.Aj[1].x, c.Aj[1].y};
+    const double Bi[NX] = {c.Bi[0].x, c.Bi[0].y, c.Bi[1].x, c.Bi[1].y}, Bj[NX] = {c.Bj[0].x, c.Bj[0].y, c.Bj[1].x, c.Bj[1].y};
+
+    // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
+    double qx_i, qu_own;
+    {
+      const double Vc[NX] = {quad_bcast<0>(Vown), quad_bcast<1>(Vown), quad_bcast<2>(Vown), quad_bcast<3>(Vown)};   // V(k, j)
+      const double vxk[NX] = {row_bcast<0>(vxi), row_bcast<1>(vxi), row_bcast<2>(vxi), row_bcast<3>(vxi)};         // v_x(k)
+      double s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Ai[k] * Vc[k];
+      T[w_atv] = s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Bi[k] * Vc[k];
+      T[w_btv] = s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Ai[k] * vxk[k];
+      qx_i = c.lx + s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Bi[k] * vxk[k];
+      qu_own = c.lu + s;
+    }
+    wave_sync();
+    // ---- pass 2 (second factors of ilqr.hpp:117-119)
+    double quu[NU * NU], qu[NU], quxj[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU], qxx_own;
+    {
+      double ra[NX], rb[NX];
+      MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[oBtV + iu * 4 + k]; }
+      double s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += ra[k] * Aj[k];
+      qxx_own = c.lxx + s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Aj[k];
+      const double qux_own = c.lux + s;
+      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Bj[k];
+      const double quu_own = c.luu + s;
+      T[oQxx + lane] = qxx_own;
+      T[w_qux] = qux_own;
+      row_gather_block<NU>(quu_own, quu, std::make_integer_sequence<int, NU * NU>{});
+      row_gather_first(qu_own, qu, std::make_integer_sequence<int, NU>{});
+      quad_gather(qux_own, quxj, std::make_integer_sequence<int, NU>{});
+    }
+    // ---- pass 3 (ilqr.hpp:172-192)
+    {
+      {
+        double cur[NU * NU];
+        MAS_UNROLL for (int e = 0; e < NU * NU; ++e) cur[e] = quu[e];
+        MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
+          MAS_UNROLL for (int e = 0; e < NU; ++e) cur[e * NU + e] += rung_add[q];
+        }
+        int win = -1;
+        if constexpr (SharedLadder) {
+          double reg_next = 0.0;
+          for (int base = 0, chunk = 0;; base += LL, ++chunk) {
+            if (chunk > 0) {
+              if (chunk == 1) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+              for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int e = 0; e < NU; ++e) cur[e * NU + e] += reg_next; reg_next *= 10.0; }
+            }
+            MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = cur[e];
+            const int ok = llt_compute<NU>(Lfac) == 0;
+            unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (!valid) field = 0xFFFFu;
+            MAS_UNROLL for (int sh = LPA; sh < 64; sh <<= 1) field &= static_cast<unsigned>(__shfl_xor(static_cast<int>(field), sh));
+            unsigned agreed;
+            if constexpr (WPB == 1) {
+              agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
+            } else {
+              const unsigned par = agreement_parity; agreement_parity ^= 1u;
+              if (tid == 0) blk_field[par][wave] = field;
+              __syncthreads();
+              unsigned bf = 0xFFFFu;
+              MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
+              if (gridDim.x == 1) {
+                agreed = bf;
+              } else {
+                if (wave == 0) {
+                  const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
+                  if (tid == 0) blk_agreed[par] = g;
+                }
+                __syncthreads();
+                agreed = blk_agreed[par];
+              }
+            }
+            if (agreed != 0u) { win = base + __builtin_ctz(agreed); break; }
+            if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; break; }
+          }
+        } else {
+          {
+            MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = cur[e];
+            const int ok = llt_compute_straight<NU>(Lfac) == 0;
+            const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (field != 0u) win = __builtin_ctz(field);
+          }
+          if (__ballot(win < 0) != 0ull) {
+            double reg_next = 0.0;
+            int base = 0;
+            for (;;) {
+              if (win < 0 && base + LL > kRegLadderMax) win = base + LL - 1;
+              if (__ballot(win < 0) == 0ull) break;
+              if (win < 0) {
+                if (base == 0) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+                for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int e = 0; e < NU; ++e) cur[e * NU + e] += reg_next; reg_next *= 10.0; }
+                base += LL;
+              }
+              double Ltry[NU * NU];
+              MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Ltry[e] = cur[e];
+              const int ok = llt_compute<NU>(Ltry) == 0;
+              const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+              if (win < 0) {
+                MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = Ltry[e];
+                if (field != 0u) win = base + __builtin_ctz(field);
+              }
+            }
+          }
+        }
+        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lfac[e]; }
+        if (lane == 0 && (!SharedLadder || a == 0)) regs += win;
+        wave_sync();                                                 // also orders the pass-2 outputs before the reads below
+        MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+      }
+      llt_solve_identity<NU>(Lfac, ninv);
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];
+      MAS_UNROLL for (int m = 0; m < NU; ++m) {
+        double s = 0.0;
+        MAS_UNROLL for (int q = 0; q < NU; ++q) s += ninv[q * NU + m] * qu[q];
+        kf[m] = s;
+      }
+      MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
+      {
+        double quxi[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) quxi[m] = T[oQux + i * NU + m];
+        const double qxx_mir = T[oQxx + j + 4 * i];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {
+          double si = 0.0, sj = 0.0;
+          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += ninv[q * NU + m] * quxi[q]; sj += ninv[q * NU + m] * quxj[q]; }
+          Ki[m] = si; Kj[m] = sj;
+        }
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {
+          double si = 0.0, sj = 0.0;
+          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += Ki[q] * quu[m * NU + q]; sj += Kj[q] * quu[m * NU + q]; }
+          ktqi[m] = si; ktqj[m] = sj;
+        }
+        double s, own, mir;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * quxj[m];
+        own = qxx_own + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * Kj[m];
+        own = own + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * Kj[m];
+        own = own + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Kj[m] * quxi[m];
+        mir = qxx_mir + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxj[m] * Ki[m];
+        mir = mir + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqj[m] * Ki[m];
+        mir = mir + s;
+        Vown = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));      // aliased in-place symmetrisation, :192
+        double vx_new;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * qu[m];
+        vx_new = qx_i + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * kf[m];
+        vx_new = vx_new + s;
+        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
+        vxi = vx_new + s;
+        MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[m], Ki[m]);
+      }
+    }
+    // (the LDS instructions of one wavefront execute in order: the next step's pass-1 writes cannot overtake these reads)
+    kff_t -= static_cast<size_t>(NU) * d.Np; Kfb_t -= static_cast<size_t>(NU) * NX * d.Np;
+  };
+  int t = d.T - 1;
+  for (; t >= 1; t -= 2) { step(t, tA, tB); step(t - 1, tB, tA); }
+  if (t == 0) step(0, tA, tB);
   if (valid && lane == 0) reg_events[a] += regs;
 }
 

@@ -29,6 +29,8 @@ struct ModelParams {
 // example sets one; models without constraints inherit these empty hooks.
 struct NoConstraints {
   static constexpr int NEQ = 0, NIN = 0;
+  // true: the dynamics have a four-lanes-per-rollout RK4 (QuadRk4, mas_kernels_hip.hpp) for launches that do not fill the chip
+  static constexpr bool kQuadRk4 = false;
   MAS_HD static void equality(const double*, const double*, double*, const ModelParams&) {}
   MAS_HD static void inequality(const double*, const double*, double*, const ModelParams&) {}
 };
@@ -45,6 +47,7 @@ struct SingleTrack : NoConstraints {
                         kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
   static constexpr bool kZeroTerminal = true;   // terminal_cost == 0 (:65): FD of it is exactly 0
   static constexpr bool kDefaultBounds = true;
+  static constexpr bool kQuadRk4 = true;        // psi and v advance without sin/cos: the four RK4 stages' sin/cos can run side by side
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
 
   // the part of f(x,u) that depends on u alone: RK4 evaluates f four times with the same zero-order-
@@ -180,6 +183,7 @@ struct SingleTrackLane : NoConstraints {
                         kAnalyticLxx = true, kAnalyticLuu = true, kAnalyticLux = false, kAnalyticTerm = false;
   static constexpr bool kZeroTerminal = true;
   static constexpr bool kDefaultBounds = true;
+  static constexpr bool kQuadRk4 = true;        // SingleTrack's dynamics
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -0.7; lb[1] = -1.0; ub[0] = 0.7; ub[1] = 1.0; }
 
   using Ctl = SingleTrack::Ctl;

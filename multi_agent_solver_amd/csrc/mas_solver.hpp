@@ -123,7 +123,7 @@ class SolverImpl final : public SolverBase {
     trial_merit = dalloc(static_cast<size_t>(kNumAlphas) * Np);
     cost = dalloc(Np); merit = dalloc(Np);
     x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
-    live_list = ialloc(Np); live_count0 = ialloc(16); solves_left = ialloc(Np);
+    live_lists[0] = ialloc(Np); live_lists[1] = ialloc(Np); live_count0 = ialloc(16); solves_left = ialloc(Np);
     active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
     reg_events = static_cast<long long*>(raw_alloc(sizeof(long long) * Np));
     counters = static_cast<long long*>(raw_alloc(sizeof(long long) * 32));
@@ -272,7 +272,7 @@ class SolverImpl final : public SolverBase {
       stats.agent_iterations += d.N;
       launch_sweep(sweep_bytes() * nact);
       launch_central_backward(backward_bytes() * nact);
-      be.template launch_2d<1>("forward", make_forward(), d.N, kNumAlphas, forward_bytes() * nact * kNumAlphas);
+      launch_forward(make_forward(), forward_bytes() * nact * kNumAlphas, nullptr, nullptr, d.N);     // every agent active: slot == agent, CommitBody serves both forms
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       be.d2h(host_central, central, sizeof(CentralState));
@@ -412,8 +412,8 @@ class SolverImpl final : public SolverBase {
   // live_count != nullptr: walk the compacted list of active agents (live_list) instead of the active flags
   void launch_sweep(double bytes) { launch_sweep(bytes, 0, d.N); }
   // slots: with a live list, an upper bound of its length (the grid covers that many list slots)
-  void launch_sweep(double bytes, int lo, int hi, const int* live_count = nullptr, int slots = 0) {
-    (void)live_count; (void)slots;
+  void launch_sweep(double bytes, int lo, int hi, const int* live_count = nullptr, int slots = 0, const int* live_list = nullptr) {
+    (void)live_count; (void)slots; (void)live_list;
 #if defined(MAS_HOST_EMULATION)
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
 #else
@@ -438,6 +438,32 @@ class SolverImpl final : public SolverBase {
                      static_cast<const int*>(live_count ? live_list : nullptr), live_count);
     be.end();
 #endif
+  }
+  // line-search rollouts.  Returns true when the trial planes were written slot-indexed (mas_forward_quad_kernel), i.e. the
+  // commit has to map slots back to agents.  One lane per rollout (ForwardBody) while the rollouts fill the chip; four lanes
+  // per rollout once they no longer do -- the tail rounds of a solve, small batches, the centralised strategy's 256 agents --
+  // where the launch time is one wavefront's chain and the quad form makes that chain ~40 % shorter.
+  // live_count: device-side length of live_list (null: every agent, slot == agent); slots: host-side upper bound of it
+  bool launch_forward(const ForwardBody<M>& fwd, double bytes, const int* live_list, const int* live_count, long long slots) {
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (M::kQuadRk4 && !kConstrained) {
+      if (slots <= quad_forward_max_slots()) {
+        be.begin("forward", bytes);
+        be.launch_kernel(mas_forward_quad_kernel<M>, dim3(static_cast<unsigned>((slots + 63) / 64), kNumAlphas), dim3(256), fwd, live_list, live_count);
+        be.end();
+        return true;
+      }
+    }
+#endif
+    (void)live_list; (void)live_count; (void)slots;
+    be.template launch_2d_range<kForwardTrialsPerBlock>("forward", fwd, 0, d.N, kNumAlphas, bytes);
+    return false;
+  }
+  // 1600 slots x 10 trials x 4 lanes = 1000 wavefronts: the most the quad form can spread one per SIMD (1024 on MI355X);
+  // beyond that its wavefronts double up and the one-lane form (640 wavefronts at 4096 agents) is faster again
+  long long quad_forward_max_slots() const {
+    if (const char* e = std::getenv("MAS_HIP_FORWARD_QUAD_MAX")) return std::atoll(e);     // experiments / tests: 0 = never, large = always
+    return 1600;
   }
   // backward pass of the stacked problem: the 16-lane tile kernel with the rung agreement across all wavefronts
   // (LadderSync); constrained models and the host emulation keep the one-workgroup body
@@ -485,13 +511,22 @@ class SolverImpl final : public SolverBase {
     be.begin("backward", bytes);
     constexpr int apw = 64 / kBackwardLanesPerAgent;
     constexpr int wpb = kBackwardWavesPerBlock;       // four wavefronts per workgroup: one per SIMD of a CU (mas_kernels_hip.hpp)
-    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false, wpb>, dim3((hi - lo + wpb * apw - 1) / (wpb * apw)), dim3(64 * wpb), d, P, X, D, kff, Kfb,
+    const dim3 grid((hi - lo + wpb * apw - 1) / (wpb * apw));
+    if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) {     // registers + DPP form (no LDS for V and the tiles)
+      if (!backward_tile_forced()) {
+        be.launch_kernel(mas_backward_row_kernel<M, false, wpb>, grid, dim3(64 * wpb), d, P, X, D, kff, Kfb, reg_events, active, lo, hi, LadderSync{});
+        be.end();
+        return;
+      }
+    }
+    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false, wpb>, grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
                      reg_events, active, lo, hi, LadderSync{});
     be.end();
 #endif
   }
 
 #if !defined(MAS_HOST_EMULATION)
+  static bool backward_tile_forced() { const char* e = std::getenv("MAS_HIP_BACKWARD_TILE"); return e && e[0] == '1'; }   // A/B: the LDS-tile kernel also for NX == 4
   // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
   // them resident at once.  Checked against the occupancy the runtime reports for this kernel on this device (a
   // partitioned device, e.g. CPX with 32 CUs, or a build with higher register use may not hold them); if they do not fit,
@@ -575,7 +610,7 @@ class SolverImpl final : public SolverBase {
     if (timed && !solve_start) solve_start = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * d.Np));
     if (debug && !dbg_iter) { dbg_iter = ialloc(d.Np); dbg_improvement = dalloc(d.Np); }
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
-                                                           counters, 2 * kCounterRing, live_list, live_count0, d.N,
+                                                           counters, 2 * kCounterRing, live_lists[0], live_count0, d.N,
                                                            solves_left, n_solves - 1, timed ? solve_start : nullptr}, d.N);
     if (!rollout_consistent) {
       be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
@@ -606,18 +641,22 @@ class SolverImpl final : public SolverBase {
       // grid: the live list only shrinks during a chain of solves, so the last count the host has read back bounds it from
       // above -- workgroups beyond the list would each be dispatched only to exit, and 1,500 of those cost a tail-round sweep
       // more than its few live workgroups do
-      launch_sweep(sweep_bytes(), 0, d.N, live, live ? static_cast<int>(live_upper) : d.N);
+      // two lists: round r walks list r & 1 (sweep, quad line search, commit) while its select compacts the next round's
+      const int* list_now = live_lists[r & 1]; int* list_next = live_lists[(r + 1) & 1];
+      launch_sweep(sweep_bytes(), 0, d.N, live, live ? static_cast<int>(live_upper) : d.N, list_now);
       launch_backward(backward_bytes(), 0, d.N);
-      be.template launch_2d_range<kForwardTrialsPerBlock>("forward", fwd, 0, d.N, kNumAlphas, forward_bytes() * kNumAlphas);
+      const bool by_slot = live ? launch_forward(fwd, forward_bytes() * kNumAlphas, list_now, live, live_upper)
+                                : launch_forward(fwd, forward_bytes() * kNumAlphas, nullptr, nullptr, std::numeric_limits<long long>::max());
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
       const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
                            iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
-                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : live_list,
+                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : list_next,
                            n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
                            debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr, trust_epilogue ? trust_ended : nullptr};
       be.template launch_1d<1>("select", sel, d.N);
-      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      if (by_slot) be.template launch_2d<4>("commit", CommitSlotBody<M>{d, Xs, Us, alpha_sel, X, U, list_now, live}, static_cast<int>(live_upper), d.T + 1);
+      else be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
       if (trust_epilogue) {
         const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
         be.template launch_1d<1>("trust_norm", TrustNormBody<M>{d, trust_ended, U, U_old, ts, trust_scale, trust_roll_list, trust_roll_count}, d.N);
@@ -722,7 +761,7 @@ class SolverImpl final : public SolverBase {
   double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
-  int *live_list = nullptr, *live_count0 = nullptr;   // agents still active, compacted by select; count of round 0 (= N)
+  int *live_lists[2] = {nullptr, nullptr}, *live_count0 = nullptr;   // agents still active, compacted by select (round r reads list r & 1, writes the other); count of round 0 (= N)
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
   int *trust_verdict = nullptr, *trust_ended = nullptr, *trust_roll_list = nullptr, *trust_roll_count = nullptr;   // chained trust-region epilogue
   double *trust_scale = nullptr;
