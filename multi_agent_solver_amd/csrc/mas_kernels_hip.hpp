@@ -721,9 +721,9 @@ __device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 
   return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
 }
 __device__ __forceinline__ double2 ld2_off(const double* base, unsigned byte_off) { return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + byte_off); }
-// out[e] = the value lane (e % NU, e / NU) of the row holds, e < NU * NU (q_uu); out[m] = lane m's (q_u); out[m] = lane m of the quad's (q_ux column)
-template <int NU, int... E>
-__device__ __forceinline__ void row_gather_block(double v, double* out, std::integer_sequence<int, E...>) { ((out[E] = row_bcast<(E % NU) + 4 * (E / NU)>(v)), ...); }
+// out[e] = the value lane (I0 + e % NU, e / NU) of the row holds, e < NU * NU (q_uu); out[m] = lane m's (q_u); out[m] = lane m of the quad's (q_ux column)
+template <int NU, int I0, int... E>
+__device__ __forceinline__ void row_gather_block_at(double v, double* out, std::integer_sequence<int, E...>) { ((out[E] = row_bcast<(I0 + E % NU) + 4 * (E / NU)>(v)), ...); }
 template <int... E>
 __device__ __forceinline__ void row_gather_first(double v, double* out, std::integer_sequence<int, E...>) { ((out[E] = row_bcast<E>(v)), ...); }
 template <int... E>
@@ -741,7 +741,14 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   constexpr int LPA = 16, APW = 4, LL = 16;
   // LDS per agent (doubles): rows of A^T V [i*4 + k], rows of B^T V [m*4 + k], q_xx [i + 4 j], q_ux columns [j*NU + m], the
   // winning factor, 16 pad slots for lanes without an item (own slot per lane: no write conflicts); stride = 16 (mod 32)
-  constexpr int oAtV = 0, oBtV = 16, oQxx = 32, oQux = 48, oL = 64, oPad = 80, STRIDE = 112;
+  constexpr int oAtV = 0, oBtV = 16, oQxx = 32, oQux = 48, oL = 64, oVx = 80, oQx = 84, oPad = 96, STRIDE = 112;
+  // NU <= 2 leaves lanes without an item in the second round of pass 2 (q_ux has 4 NU items): they take q_uu and q_x, which
+  // saves a dot product in each of the two passes.  Second-round item of lane (i, j), all of the form bias + row . column with
+  // the row read from LDS and the column loaded from the tile:
+  //    i < NU           q_ux(i, j)      = l_ux + (B^T V)(i, :) . A(:, j)
+  //    i >= 2, j < NU   q_uu(i-2, j)    = l_uu + (B^T V)(i-2, :) . B(:, j)          [i - 2 < NU]
+  //    i >= 2, j >= 2   q_x(c)          = l_x  + v_x . A(:, c),  c = (i-2) + 2 (j-2)   (v_x kept in LDS for this)
+  constexpr bool kMerged = NU <= 2;
   __shared__ double lds[WPB * APW * STRIDE];
   __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];
   __shared__ unsigned blk_agreed[2];
@@ -764,11 +771,11 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
     double xT[NX], vx[NX], vxx[NX * NX];
     MAS_UNROLL for (int q = 0; q < NX; ++q) xT[q] = MAS_AT(X, d.T * NX + q, a);
     terminal_boundary<M>(xT, vx, vxx, P);
-    MAS_UNROLL for (int q = 0; q < NX; ++q) T[oAtV + q] = vx[q];
+    MAS_UNROLL for (int q = 0; q < NX; ++q) T[oVx + q] = vx[q];
     MAS_UNROLL for (int q = 0; q < NX * NX; ++q) T[oQxx + q] = vxx[q];
   }
   wave_sync();
-  double Vown = T[oQxx + lane], vxi = T[oAtV + i];
+  double Vown = T[oQxx + lane], vxi = T[oVx + i];
   wave_sync();
 
   // this lane's operands of one tile: loop-invariant 32-bit byte offsets under a uniform base that steps back one time step
@@ -779,6 +786,16 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   unsigned oAi = elem_off(L::oA + 4 * i), oAj = elem_off(L::oA + 4 * j), oBi = elem_off(L::oB + 4 * iu), oBj = elem_off(L::oB + 4 * ju);
   unsigned olx = elem_off(L::oLx + i), olu = elem_off(L::oLu + iu), olxx = elem_off(L::oLxx + lane), olux = elem_off(L::oLux + iu + NU * j),
            oluu = elem_off(L::oLuu + iu + NU * ju);
+  // merged second round: its column (in the Bj slot) and bias (in the lux slot) are this lane's item's; its LDS row address
+  const int item2 = (i < NU) ? 0 : ((i >= 2 && j < NU && i - 2 < NU) ? 1 : ((i >= 2 && j >= 2) ? 2 : 3));   // q_ux, q_uu, q_x, none
+  const int c2 = (i - 2) + 2 * (j - 2);
+  int r_row2 = oBtV + iu * 4;
+  if constexpr (kMerged) {
+    if (item2 == 0) { oBj = oAj; }
+    else if (item2 == 1) { oBj = elem_off(L::oB + 4 * j); olux = elem_off(L::oLuu + (i - 2) + NU * j); r_row2 = oBtV + (i - 2) * 4; }
+    else if (item2 == 2) { oBj = elem_off(L::oA + 4 * c2); olux = elem_off(L::oLx + c2); r_row2 = oVx; }
+    else { oBj = oAj; r_row2 = oBtV; }
+  }
   struct Tile { double2 Ai[2], Aj[2], Bi[2], Bj[2]; double lx, lu, lxx, lux, luu; };
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
   // (the 64-agent block of a wavefront is uniform: said explicitly, so that the base pointer lives in scalar registers)
@@ -788,7 +805,8 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
     o.Aj[0] = ld2_off(tiles_t, oAj); o.Aj[1] = ld2_off(tiles_t, oAj + 16);
     o.Bi[0] = ld2_off(tiles_t, oBi); o.Bi[1] = ld2_off(tiles_t, oBi + 16);
     o.Bj[0] = ld2_off(tiles_t, oBj); o.Bj[1] = ld2_off(tiles_t, oBj + 16);
-    o.lx = ld_off(tiles_t, olx); o.lu = ld_off(tiles_t, olu); o.lxx = ld_off(tiles_t, olxx); o.lux = ld_off(tiles_t, olux); o.luu = ld_off(tiles_t, oluu);
+    o.lu = ld_off(tiles_t, olu); o.lxx = ld_off(tiles_t, olxx); o.lux = ld_off(tiles_t, olux);
+    if constexpr (!kMerged) { o.lx = ld_off(tiles_t, olx); o.luu = ld_off(tiles_t, oluu); }
   };
   long long regs = 0;
   double rung_add[LL - 1];
@@ -803,7 +821,8 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
   // LDS addresses of this lane (a lane without an item writes its own pad slot)
   const int w_atv = oAtV + i * 4 + j, w_btv = (i < NU) ? (oBtV + i * 4 + j) : (oPad + lane);
-  const int w_qux = (i < NU) ? (oQux + j * NU + i) : (oPad + lane);
+  const int w_qux = (i < NU) ? (oQux + j * NU + i) : ((kMerged && item2 == 2) ? (oQx + c2) : (oPad + lane));
+  const int w_vx = (j == 0) ? (oVx + i) : (oPad + lane);
 
   Tile tA, tB;
   fetch(tA);
@@ -826,8 +845,10 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
       T[w_atv] = s;
       s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Bi[k] * Vc[k];
       T[w_btv] = s;
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Ai[k] * vxk[k];
-      qx_i = c.lx + s;
+      if constexpr (!kMerged) {
+        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Ai[k] * vxk[k];
+        qx_i = c.lx + s;
+      }
       s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Bi[k] * vxk[k];
       qu_own = c.lu + s;
     }
@@ -836,19 +857,27 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
     double quu[NU * NU], qu[NU], quxj[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU], qxx_own;
     {
       double ra[NX], rb[NX];
-      MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[oBtV + iu * 4 + k]; }
+      MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
       double s;
       s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += ra[k] * Aj[k];
       qxx_own = c.lxx + s;
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Aj[k];
-      const double qux_own = c.lux + s;
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Bj[k];
-      const double quu_own = c.luu + s;
       T[oQxx + lane] = qxx_own;
-      T[w_qux] = qux_own;
-      row_gather_block<NU>(quu_own, quu, std::make_integer_sequence<int, NU * NU>{});
+      if constexpr (kMerged) {
+        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Bj[k];          // this lane's second-round item (see kMerged)
+        const double item = c.lux + s;
+        T[w_qux] = item;
+        row_gather_block_at<NU, 2>(item, quu, std::make_integer_sequence<int, NU * NU>{});   // q_uu(m, n) from lane (2 + m, n)
+        quad_gather(item, quxj, std::make_integer_sequence<int, NU>{});
+      } else {
+        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Aj[k];
+        const double qux_own = c.lux + s;
+        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Bj[k];
+        const double quu_own = c.luu + s;
+        T[w_qux] = qux_own;
+        row_gather_block_at<NU, 0>(quu_own, quu, std::make_integer_sequence<int, NU * NU>{});
+        quad_gather(qux_own, quxj, std::make_integer_sequence<int, NU>{});
+      }
       row_gather_first(qu_own, qu, std::make_integer_sequence<int, NU>{});
-      quad_gather(qux_own, quxj, std::make_integer_sequence<int, NU>{});
     }
     // ---- pass 3 (ilqr.hpp:172-192)
     {
@@ -940,6 +969,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
         double quxi[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
         MAS_UNROLL for (int m = 0; m < NU; ++m) quxi[m] = T[oQux + i * NU + m];
         const double qxx_mir = T[oQxx + j + 4 * i];
+        if constexpr (kMerged) qx_i = T[oQx + i];
         MAS_UNROLL for (int m = 0; m < NU; ++m) {
           double si = 0.0, sj = 0.0;
           MAS_UNROLL for (int q = 0; q < NU; ++q) { si += ninv[q * NU + m] * quxi[q]; sj += ninv[q * NU + m] * quxj[q]; }
@@ -971,6 +1001,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
         vx_new = vx_new + s;
         s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
         vxi = vx_new + s;
+        if constexpr (kMerged) T[w_vx] = vxi;                       // pass 2 of the next step reads v_x as an LDS row
         MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[m], Ki[m]);
       }
     }
