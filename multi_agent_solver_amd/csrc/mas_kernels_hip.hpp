@@ -319,48 +319,37 @@ struct BackwardTileLayout {
 //            in-place symmetrisation rule, so no further exchange is needed.
 // Rung agreement of the centralised strategy (SharedLadder): the stacked q_uu is block-diagonal, its LLT fails if
 // ANY block fails and reg*I is then added to EVERY block (ilqr.hpp:172-182), so all agents use the first rung at
-// which all of them succeed.  Per (time step, chunk of 16 rungs) there are three 64-bit words; every wavefront adds
-// to each of them, with ONE fire-and-forget atomic, 1 to an arrival counter (bits 54..62) and 1 to the 9-bit
-// counter of every rung of that word at which one of its agents failed (six rungs per word), then polls the three
-// words until each arrival counter shows all wavefronts: a rung is agreed on when its failure counter is zero.
-// Every word carries its own arrival counter because the three atomics may complete in any order.  Cost: one
-// atomic flight plus one or two polls per time step, no fence.  The launch is at most 256 single-wavefront
-// workgroups (1024 agents), all resident at once, so the wait always ends; it is bounded anyway (a wavefront that
-// gives up raises *error, every later wait returns at once, and the host reports it).
+// which all of them succeed.  Per (time step, chunk of 16 rungs) there is ONE 64-bit word: every wavefront ORs the rungs
+// at which one of its agents failed into bits 0..15 and then adds 1 to the arrival counter in bits 32.., both
+// fire-and-forget, and polls the word until the counter shows all wavefronts: a rung is agreed on when its bit is clear.
+// The OR precedes the arrival in the word's modification order because both come from one lane (coherence of a single
+// location follows program order), so a complete counter implies a complete mask.  tools/ubench/xcd_barrier.hip measures the
+// bare arrive-and-wait of 16 workgroups at 0.87 us (0.72 us when they share an XCD); round 2's three words with 9-bit failure
+// counters, behind a workgroup-level combination with two barriers, cost ~2 us per time step.
+// The launch is at most 256 workgroups, all resident at once (checked on the host), so the wait always ends; it is bounded
+// anyway (a wavefront that gives up raises *error, every later wait returns at once, and the host reports it).
 struct LadderSync {
-  unsigned long long* words = nullptr;   // [T * kChunks][4] (three used), preset to zero
+  unsigned long long* words = nullptr;   // [T * kChunks][4] (one used), preset to zero
   int* error = nullptr;
-  static constexpr int kChunks = 32, kRungsPerWord = 6, kFieldBits = 9, kArrivalShift = 54;
+  int combine = 1;                       // workgroups of several wavefronts: combine their masks through LDS and arrive once per workgroup (measured on C2, us per pass: 245 against 546 when each of the 64 wavefronts arrives itself; single-wavefront workgroups: 253)
+  static constexpr int kChunks = 32, kArrivalShift = 32;
 };
 __device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned wave_ok_mask, int n_waves) {
   unsigned agreed = 0u;
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* w = sy.words + static_cast<size_t>(slot) * 4;
-    const unsigned fail = ~wave_ok_mask & 0xFFFFu;
-    MAS_UNROLL for (int k = 0; k < 3; ++k) {
-      unsigned long long add = 1ull << LadderSync::kArrivalShift;
-      MAS_UNROLL for (int i = 0; i < LadderSync::kRungsPerWord; ++i) {
-        const int r = k * LadderSync::kRungsPerWord + i;
-        if (r < 16 && ((fail >> r) & 1u)) add += 1ull << (LadderSync::kFieldBits * i);
-      }
-      atomicAdd(w + k, add);
-    }
-    unsigned long long v[3] = {0ull, 0ull, 0ull};
+    const unsigned long long fail = ~wave_ok_mask & 0xFFFFu;
+    if (fail != 0ull) __hip_atomic_fetch_or(w, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(w, 1ull << LadderSync::kArrivalShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v = 0ull;
     int spins = 0;
     for (;;) {
-      bool all = true;
-      MAS_UNROLL for (int k = 0; k < 3; ++k) {
-        v[k] = __atomic_load_n(w + k, __ATOMIC_RELAXED);
-        all = all && static_cast<int>((v[k] >> LadderSync::kArrivalShift) & 0x1FFull) == n_waves;
-      }
-      if (all) break;
-      if (++spins > (1 << 18) || __atomic_load_n(sy.error, __ATOMIC_RELAXED) != 0) { atomicExch(sy.error, 1); break; }   // ~0.3 s, once per launch
+      v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (static_cast<int>(v >> LadderSync::kArrivalShift) == n_waves) break;
+      if (++spins > (1 << 18) || __hip_atomic_load(sy.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicExch(sy.error, 1); break; }   // ~0.3 s, once per launch
       __builtin_amdgcn_s_sleep(1);
     }
-    MAS_UNROLL for (int r = 0; r < 16; ++r) {
-      const unsigned long long f = (v[r / LadderSync::kRungsPerWord] >> (LadderSync::kFieldBits * (r % LadderSync::kRungsPerWord))) & 0x1FFull;
-      if (f == 0ull) agreed |= 1u << r;
-    }
+    agreed = static_cast<unsigned>(~v) & 0xFFFFu;
   }
   return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(agreed)));
 }
@@ -567,23 +556,30 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
             unsigned agreed;
             if constexpr (WPB == 1) {
               agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
-            } else {
-              // workgroup first (LDS + one barrier), then one wavefront per workgroup across workgroups (if there are several)
+            } else if (gridDim.x == 1) {
+              // one workgroup holds the whole problem: LDS and one barrier
               const unsigned par = agreement_parity; agreement_parity ^= 1u;
               if (tid == 0) blk_field[par][wave] = field;
               __syncthreads();
               unsigned bf = 0xFFFFu;
               MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
-              if (gridDim.x == 1) {
-                agreed = bf;
-              } else {
-                if (wave == 0) {
-                  const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
-                  if (tid == 0) blk_agreed[par] = g;
-                }
-                __syncthreads();
-                agreed = blk_agreed[par];
+              agreed = bf;
+            } else if (sync.combine != 0) {
+              // workgroup first (LDS + one barrier), then one wavefront per workgroup across workgroups
+              const unsigned par = agreement_parity; agreement_parity ^= 1u;
+              if (tid == 0) blk_field[par][wave] = field;
+              __syncthreads();
+              if (wave == 0) {
+                unsigned bf = 0xFFFFu;
+                MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
+                const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
+                if (tid == 0) blk_agreed[par] = g;
               }
+              __syncthreads();
+              agreed = blk_agreed[par];
+            } else {
+              // every wavefront of the launch arrives on its own: no workgroup barrier on the way in or out
+              agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x) * WPB);
             }
             if (agreed != 0u) { win = base + __builtin_ctz(agreed); break; }
             if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; break; }   // guard, never reached (see kRegLadderMax)
@@ -903,22 +899,30 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
             unsigned agreed;
             if constexpr (WPB == 1) {
               agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
-            } else {
+            } else if (gridDim.x == 1) {
+              // one workgroup holds the whole problem: LDS and one barrier
               const unsigned par = agreement_parity; agreement_parity ^= 1u;
               if (tid == 0) blk_field[par][wave] = field;
               __syncthreads();
               unsigned bf = 0xFFFFu;
               MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
-              if (gridDim.x == 1) {
-                agreed = bf;
-              } else {
-                if (wave == 0) {
-                  const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
-                  if (tid == 0) blk_agreed[par] = g;
-                }
-                __syncthreads();
-                agreed = blk_agreed[par];
+              agreed = bf;
+            } else if (sync.combine != 0) {
+              // workgroup first (LDS + one barrier), then one wavefront per workgroup across workgroups
+              const unsigned par = agreement_parity; agreement_parity ^= 1u;
+              if (tid == 0) blk_field[par][wave] = field;
+              __syncthreads();
+              if (wave == 0) {
+                unsigned bf = 0xFFFFu;
+                MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
+                const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
+                if (tid == 0) blk_agreed[par] = g;
               }
+              __syncthreads();
+              agreed = blk_agreed[par];
+            } else {
+              // every wavefront of the launch arrives on its own: no workgroup barrier on the way in or out
+              agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x) * WPB);
             }
             if (agreed != 0u) { win = base + __builtin_ctz(agreed); break; }
             if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; break; }

@@ -474,7 +474,8 @@ class SolverImpl final : public SolverBase {
       const size_t words = static_cast<size_t>(d.T) * LadderSync::kChunks * 4;
       if (!ladder_sync) ladder_sync = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * (words + 2)));
       MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
-      const LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
+      LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
+      if (const char* e = std::getenv("MAS_HIP_CENTRAL_COMBINE")) sy.combine = std::atoi(e);
       constexpr int apw = 64 / kBackwardLanesPerAgent;
       be.begin("central_backward", bytes);
       const int wpb = central_waves_per_block();
@@ -483,11 +484,11 @@ class SolverImpl final : public SolverBase {
         be.launch_kernel(kernel, dim3((d.N + agents_per_block - 1) / agents_per_block), dim3(64 * w), d, P, X, D, kff, Kfb,
                          reg_events, active, 0, static_cast<int>(d.N), sy);
       };
-      if (wpb == 16) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 16>, 16);
-      else if (wpb == 8) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 8>, 8);
-      else if (wpb == 4) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 4>, 4);
-      else if (wpb == 2) launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 2>, 2);
-      else launch(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 1>, 1);
+      if (wpb == 16) launch(central_kernel<16>(), 16);
+      else if (wpb == 8) launch(central_kernel<8>(), 8);
+      else if (wpb == 4) launch(central_kernel<4>(), 4);
+      else if (wpb == 2) launch(central_kernel<2>(), 2);
+      else launch(central_kernel<1>(), 1);
       be.end();
       ladder_error_pending = true;
       return;
@@ -526,6 +527,13 @@ class SolverImpl final : public SolverBase {
   }
 
 #if !defined(MAS_HOST_EMULATION)
+  // the backward kernel with the shared ladder, W wavefronts per workgroup: the registers + DPP form for NX == 4, else the LDS-tile form
+  using BackwardKernelFn = void (*)(Dims, ModelParams, const double*, const double*, double*, double*, long long*, const int*, int, int, LadderSync);
+  template <int W>
+  static BackwardKernelFn central_kernel() {
+    if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) { if (!backward_tile_forced()) return mas_backward_row_kernel<M, true, W>; }
+    return mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, W>;
+  }
   static bool backward_tile_forced() { const char* e = std::getenv("MAS_HIP_BACKWARD_TILE"); return e && e[0] == '1'; }   // A/B: the LDS-tile kernel also for NX == 4
   // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
   // them resident at once.  Checked against the occupancy the runtime reports for this kernel on this device (a
@@ -545,11 +553,11 @@ class SolverImpl final : public SolverBase {
     const int grid = (d.N + apw * wpb - 1) / (apw * wpb);
     int per_cu = 0; hipDeviceProp_t prop;
     hipError_t q = hipErrorUnknown;
-    if (wpb == 16) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 16>, 64 * 16, 0);
-    else if (wpb == 8) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 8>, 64 * 8, 0);
-    else if (wpb == 4) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 4>, 64 * 4, 0);
-    else if (wpb == 2) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 2>, 64 * 2, 0);
-    else q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, 1>, 64, 0);
+    if (wpb == 16) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<16>(), 64 * 16, 0);
+    else if (wpb == 8) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<8>(), 64 * 8, 0);
+    else if (wpb == 4) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<4>(), 64 * 4, 0);
+    else if (wpb == 2) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<2>(), 64 * 2, 0);
+    else q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<1>(), 64, 0);
     if (q != hipSuccess || hipGetDeviceProperties(&prop, be.device) != hipSuccess) { (void)hipGetLastError(); ladder_resident_ok = false; return false; }
     ladder_resident_ok = static_cast<long long>(per_cu) * prop.multiProcessorCount >= grid;
     if (const char* f = std::getenv("MAS_HIP_FORCE_SINGLE_WORKGROUP_CENTRAL")) { if (f[0] == '1') ladder_resident_ok = false; }   // tests: exercise the fallback
