@@ -70,6 +70,7 @@ struct CentralBackwardBody {
   const double* X; const double* D;
   double* kff; double* Kfb; long long* reg_events;
   const double* Dsoa;      // [T*ND][Np] agent-fastest copy of the tiles (GPU path); the emulation reads the tiles
+  const int* active = nullptr;   // non-null: active[0] == 0 means the stacked solve has ended (an iteration enqueued behind the last one)
 
   struct AgentState { double vx[M::NX], vxx[M::NX * M::NX]; };
 
@@ -124,6 +125,7 @@ struct CentralBackwardBody {
     constexpr int NU = M::NU, ND = L::ND;
     const int a = threadIdx.x;
     const bool valid = a < n;
+    if (active && active[0] == 0) return;               // uniform
     AgentState s; QFunction<M> q;
     if (valid) begin(a, s);
     long long regs = 0;
@@ -160,6 +162,10 @@ struct CentralBackwardBody {
 struct CentralSelectBody {
   Dims d; double tolerance;
   const double* trial_merit; double* cost; double* merit; int* alpha_sel; int* iters_total; CentralState* st;
+  // non-null: the host enqueues iterations ahead of reading `done` back.  The iteration that terminates the solve clears every
+  // agent's flag, which turns the kernels of an iteration enqueued behind it into no-ops (sweep, line search: no active agent;
+  // backward pass: active[0]; this body: st->done; commit: alpha_sel = -1).
+  int* active = nullptr;
 
   MAS_HD static void decide(const double* sums, double tolerance, CentralState* st) {
     const double cur = st->cur_total;
@@ -184,15 +190,17 @@ struct CentralSelectBody {
     __shared__ double sums[kNumAlphas];
     __shared__ int sel_sh;
     const int tid = threadIdx.x;
+    if (st->done != 0) { if (tid < n) alpha_sel[tid] = -1; return; }      // an iteration enqueued behind the last one (uniform: nobody has written st yet)
     const int wave = tid >> 6, n_waves = (static_cast<int>(blockDim.x) + 63) >> 6;
     for (int j = wave; j < kNumAlphas; j += n_waves) {                  // one wavefront per alpha trial (several trials per wavefront if the block is small)
       const double s = wave_serial_sum(trial_merit + static_cast<size_t>(j) * d.Np, n);
       if ((tid & 63) == 0) sums[j] = s;
     }
     __syncthreads();
-    if (tid == 0) { decide(sums, tolerance, st); sel_sh = st->j_sel; }
+    __shared__ int done_sh;
+    if (tid == 0) { decide(sums, tolerance, st); sel_sh = st->j_sel; done_sh = st->done; }
     __syncthreads();
-    if (tid < n) apply(tid, sel_sh);
+    if (tid < n) { apply(tid, sel_sh); if (active && done_sh) active[tid] = 0; }
   }
 #endif
 };

@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
   const bool act = slot < n_live;
   const int src = act ? slot : slot0;
   const int a = live_list ? live_list[src] : src;
+  if (__ballot(f.active[a] != 0) == 0ull) return;                      // listed agents are active; without a list this is the "solve has ended" exit
   const int j = static_cast<int>(blockIdx.y);
   double alpha = 1.0;
   for (int q = 0; q < j; ++q) alpha *= 0.5;
@@ -392,6 +393,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
   const bool valid = (a < n) && active[a] != 0;
   if (!SharedLadder && __ballot(valid) == 0ull) return;   // uniform for the (single-wave) block; a shared ladder needs every wavefront
+  if (SharedLadder && active[lo] == 0) return;             // the stacked solve has ended (all flags fall together): uniform over the whole launch
   const int tile = wave * APW + slot;
   double* T = lds + tile * TL::STRIDE;
   // the tiles of a wavefront are private to it: what separates its LDS writes from its own later reads is the order in which
@@ -756,6 +758,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
   const bool valid = (a < n) && active[a] != 0;
   if (!SharedLadder && __ballot(valid) == 0ull) return;
+  if (SharedLadder && active[lo] == 0) return;             // the stacked solve has ended (all flags fall together): uniform over the whole launch
   double* T = lds + (wave * APW + slot) * STRIDE;
   auto wave_sync = [] {
     if constexpr (WPB == 1) __syncthreads();

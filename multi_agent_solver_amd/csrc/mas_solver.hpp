@@ -137,7 +137,7 @@ class SolverImpl final : public SolverBase {
     const size_t stage_elems = static_cast<size_t>(d.N) * std::max<size_t>(static_cast<size_t>(T + 1) * NX, static_cast<size_t>(T) * std::max(L::ND, NU * NX));
     stage = dalloc(stage_elems);
     host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 32));
-    host_central = static_cast<CentralState*>(be.alloc_pinned(sizeof(CentralState)));
+    host_central = static_cast<CentralState*>(be.alloc_pinned(2 * sizeof(CentralState)));   // two read-back slots (the centralised loop runs one iteration ahead)
     be.sync();
   }
   ~SolverImpl() override {
@@ -266,20 +266,51 @@ class SolverImpl final : public SolverBase {
     stats.solves += 1;
     const auto t0 = std::chrono::steady_clock::now();
     int exit_reason = kExitMaxIter;
-    for (int iter = 0; iter < max_iterations; ++iter) {
-      if (timed_out(t0)) { exit_reason = kExitTime; break; }
+    // One iteration = sweep -> backward -> line search -> select -> commit + a read-back of the solve's state.  Like solve_all
+    // the host runs one iteration AHEAD of the device: iteration r+1 is enqueued before the read-back of r is awaited; if r
+    // turns out to have ended the solve, the kernels enqueued behind it find no active agent (CentralSelectBody::active).
+    // A finite max_ms is checked at the top of every iteration (ilqr.hpp:84-90) and keeps the loop in step with the device.
+    if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
+#if defined(MAS_HOST_EMULATION)
+    const bool run_ahead = false;
+#else
+    const bool run_ahead = std::isinf(max_ms) && max_ms > 0 && !debug;
+#endif
+    struct Marks { size_t p0, p1, s0, s1; };
+    Marks marks[2];
+    int enq = 0;
+    auto enqueue = [&]() {
+      Marks& mk = marks[enq & 1];
+      mk.p0 = be.mark(); mk.s0 = stamp_launches.size();
       const double nact = static_cast<double>(d.N);
-      stats.agent_iterations += d.N;
       launch_sweep(sweep_bytes() * nact);
       launch_central_backward(backward_bytes() * nact);
       launch_forward(make_forward(), forward_bytes() * nact * kNumAlphas, nullptr, nullptr, d.N);     // every agent active: slot == agent, CommitBody serves both forms
-      be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central}, d.N);
+      be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr}, d.N);
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
-      be.d2h(host_central, central, sizeof(CentralState));
-      check_ladder_sync();
+      be.d2h_async(host_central + (enq & 1), central, sizeof(CentralState));
+      be.record(round_ev[enq & 1]);
+      mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
+      ++enq;
+    };
+    if (max_iterations > 0) { if (timed_out(t0)) exit_reason = kExitTime; else enqueue(); }
+    for (int r = 0; r < enq; ++r) {
+      if (run_ahead && enq == r + 1 && enq < max_iterations) enqueue();
+      be.wait(round_ev[r & 1]);
+      stats.agent_iterations += d.N;
       stats.batch_iterations++;
-      if (host_central->done) { exit_reason = kExitConverged; break; }
+      if (host_central[r & 1].done) {
+        exit_reason = kExitConverged;
+        if (enq > r + 1) {                               // the iteration enqueued ahead runs on no agent: nothing to account
+          be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0);
+          for (size_t q = marks[(r + 1) & 1].s0; q < marks[(r + 1) & 1].s1; ++q) stamp_launches[q].bytes = 0.0;
+        }
+        break;
+      }
+      if (enq == r + 1 && enq < max_iterations) { if (timed_out(t0)) { exit_reason = kExitTime; break; } enqueue(); }
     }
+    if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);      // drain an iteration that ran ahead
+    check_ladder_sync();
     be.d2h(host_central, central, sizeof(CentralState));
     central_total = host_central->cur_total; last_total_valid = true;
     if (exit_reason == kExitConverged) stats.converged_solves += 1;
@@ -497,7 +528,7 @@ class SolverImpl final : public SolverBase {
 #endif
     if (!Dsoa) Dsoa = dalloc(static_cast<size_t>(d.T) * L::ND * d.Np);
     be.template launch_2d<4>("tiles_to_soa", TilesToSoaBody{d, L::ND, D, Dsoa}, d.N, d.T);
-    be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, Dsoa}, d.N, bytes);
+    be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, Dsoa, active}, d.N, bytes);
   }
   // backward Riccati pass: 16 lanes per agent over LDS tiles on the GPU, scalar body in the emulation
   void launch_backward(double bytes) { launch_backward(bytes, 0, d.N); }
