@@ -371,13 +371,23 @@ struct SelectBody {
 };
 
 // copy the accepted trial into the current trajectory (x = best_x; u = best_u, ilqr.hpp:231-232)
+// Read-back of a round's counters: the commit is the last kernel of a round and runs after select has finished counting, so its
+// first lane copies the counter pair (or the stacked solve's state) into host-visible pinned memory -- a copy engine / copy
+// kernel per round (hipMemcpyAsync: ~4 us of kernel + ~6 us of gap in the trace) would sit on every round's critical path.
+struct Publish {
+  const long long* src = nullptr; long long* host = nullptr; int words = 0;
+  MAS_HD void operator()() const { for (int i = 0; i < words; ++i) host[i] = src[i]; }
+};
+
 template <class M>
 struct CommitBody {
   Dims d;
   const double* Xs; const double* Us; const int* alpha_sel;
   double* X; double* U;
+  Publish publish{};
   MAS_HD void operator()(int a, int t) const {
     constexpr int NX = M::NX, NU = M::NU;
+    if (a == 0 && t == 0 && publish.host) publish();
     const int j = alpha_sel[a];
     if (j < 0) return;
     const double* Xj = Xs + static_cast<size_t>(j) * (d.T + 1) * NX * d.Np;
@@ -395,8 +405,10 @@ struct CommitSlotBody {
   const double* Xs; const double* Us; const int* alpha_sel;
   double* X; double* U;
   const int* live_list; const int* live_count;
+  Publish publish{};
   MAS_HD void operator()(int slot, int t) const {
     constexpr int NX = M::NX, NU = M::NU;
+    if (slot == 0 && t == 0 && publish.host) publish();
     if (live_count && slot >= *live_count) return;
     const int a = live_list ? live_list[slot] : slot;
     const int j = alpha_sel[a];

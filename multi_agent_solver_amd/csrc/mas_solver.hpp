@@ -287,8 +287,9 @@ class SolverImpl final : public SolverBase {
       launch_central_backward(backward_bytes() * nact);
       launch_forward(make_forward(), forward_bytes() * nact * kNumAlphas, nullptr, nullptr, d.N);     // every agent active: slot == agent, CommitBody serves both forms
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr}, d.N);
-      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
-      be.d2h_async(host_central + (enq & 1), central, sizeof(CentralState));
+      static_assert(sizeof(CentralState) % sizeof(long long) == 0, "published word by word");
+      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U,
+                               Publish{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long))}}, d.N, d.T + 1);
       be.record(round_ev[enq & 1]);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
       ++enq;
@@ -694,8 +695,11 @@ class SolverImpl final : public SolverBase {
                            n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
                            debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr, trust_epilogue ? trust_ended : nullptr};
       be.template launch_1d<1>("select", sel, d.N);
-      if (by_slot) be.template launch_2d<4>("commit", CommitSlotBody<M>{d, Xs, Us, alpha_sel, X, U, list_now, live}, static_cast<int>(live_upper), d.T + 1);
-      else be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U}, d.N, d.T + 1);
+      // the round's counters reach the host through the commit kernel (Publish); the multiplier update of constrained models
+      // still changes them after the commit, so those rounds keep the copy
+      const Publish pub = al_round ? Publish{} : Publish{ctr, host_counters + 2 * (r % kCounterRing), 2};
+      if (by_slot) be.template launch_2d<4>("commit", CommitSlotBody<M>{d, Xs, Us, alpha_sel, X, U, list_now, live, pub}, static_cast<int>(live_upper), d.T + 1);
+      else be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
       if (trust_epilogue) {
         const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
         be.template launch_1d<1>("trust_norm", TrustNormBody<M>{d, trust_ended, U, U_old, ts, trust_scale, trust_roll_list, trust_roll_count}, d.N);
@@ -708,7 +712,7 @@ class SolverImpl final : public SolverBase {
                                                                X, U, improvement, al_view(true), active, iters_solve, exit_code,
                                                                reinterpret_cast<int*>(ctr), ctr + 1, timed ? solve_start : nullptr, max_ms}, d.N);
       }
-      be.d2h_async(host_counters + 2 * (r % kCounterRing), ctr, sizeof(long long) * 2);
+      if (al_round) be.d2h_async(host_counters + 2 * (r % kCounterRing), ctr, sizeof(long long) * 2);
       be.record(round_ev[r & 1]);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
     };
