@@ -191,7 +191,7 @@ struct QuadRk4<SingleTrack> {
     const double h = (s == 3) ? dt : (0.5 * dt);                       // x + (0.5*dt)*k1, x + (0.5*dt)*k2, x + dt*k3
     const double hv = x[3] + h * a;
     const double vs = (s == 0) ? x[3] : hv;                             // stage 0 evaluates f at x itself
-    const double kpsi = vs * c.tan_delta / L;                          // dynamics_c: d[2]
+    const double kpsi = div_by(vs * c.tan_delta, make_inv_div(L));     // dynamics_c: d[2]
     const double hp = x[2] + h * quad_from_prev(kpsi);
     const double psis = (s == 0) ? x[2] : hp;
     double sn, cs;

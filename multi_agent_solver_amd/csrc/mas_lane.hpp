@@ -71,7 +71,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     MAS_UNROLL for (int i = 0; i < NX; ++i) {
       perturb1<NX>(x, i, +eps, xp); M::dynamics(xp, u, fp, P);
       perturb1<NX>(x, i, -eps, xm); M::dynamics(xm, u, fm, P);
-      MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oA + i * NX + r] = (fp[r] - fm[r]) / (2 * eps);
+      MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oA + i * NX + r] = div_by(fp[r] - fm[r], make_inv_div(2 * eps));
     }
   }
   if constexpr (M::kAnalyticB) {
@@ -81,7 +81,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     MAS_UNROLL for (int i = 0; i < NU; ++i) {
       perturb1<NU>(u, i, +eps, up); M::dynamics(x, up, fp, P);
       perturb1<NU>(u, i, -eps, um); M::dynamics(x, um, fm, P);
-      MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oB + i * NX + r] = (fp[r] - fm[r]) / (2 * eps);
+      MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oB + i * NX + r] = div_by(fp[r] - fm[r], make_inv_div(2 * eps));
     }
   }
   if constexpr (M::kAnalyticLx) {
@@ -90,7 +90,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     const double eps = 1e-6;
     MAS_UNROLL for (int i = 0; i < NX; ++i) {
       perturb1<NX>(x, i, +eps, xp); perturb1<NX>(x, i, -eps, xm);
-      D[L::oLx + i] = (M::stage_cost(xp, u, t, P) - M::stage_cost(xm, u, t, P)) / (2 * eps);
+      D[L::oLx + i] = div_by(M::stage_cost(xp, u, t, P) - M::stage_cost(xm, u, t, P), make_inv_div(2 * eps));
     }
   }
   if constexpr (M::kAnalyticLu) {
@@ -99,7 +99,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     const double eps = 1e-6;
     MAS_UNROLL for (int i = 0; i < NU; ++i) {
       perturb1<NU>(u, i, +eps, up); perturb1<NU>(u, i, -eps, um);
-      D[L::oLu + i] = (M::stage_cost(x, up, t, P) - M::stage_cost(x, um, t, P)) / (2 * eps);
+      D[L::oLu + i] = div_by(M::stage_cost(x, up, t, P) - M::stage_cost(x, um, t, P), make_inv_div(2 * eps));
     }
   }
   if constexpr (M::kAnalyticLxx) {
@@ -111,7 +111,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       const double f_plus = safe_value(M::stage_cost(xp, u, t, P));
       const double f = safe_value(M::stage_cost(x, u, t, P));
       const double f_minus = safe_value(M::stage_cost(xm, u, t, P));
-      D[L::oLxx + i * NX + i] = (f_plus - 2 * f + f_minus) / (eps * eps);
+      D[L::oLxx + i * NX + i] = div_by(f_plus - 2 * f + f_minus, make_inv_div(eps * eps));
     }
     MAS_UNROLL for (int i = 0; i < NX; ++i) {
       MAS_UNROLL for (int j = 0; j < NX; ++j) {
@@ -120,7 +120,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
           perturb2<NX>(x, i, +eps, j, -eps, xp); const double f_pm = safe_value(M::stage_cost(xp, u, t, P));
           perturb2<NX>(x, i, -eps, j, +eps, xp); const double f_mp = safe_value(M::stage_cost(xp, u, t, P));
           perturb2<NX>(x, i, -eps, j, -eps, xp); const double f_mm = safe_value(M::stage_cost(xp, u, t, P));
-          D[L::oLxx + j * NX + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+          D[L::oLxx + j * NX + i] = div_by(f_pp - f_pm - f_mp + f_mm, make_inv_div(4 * eps * eps));
         }
       }
     }
@@ -134,7 +134,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       const double f_plus = safe_value(M::stage_cost(x, up, t, P));
       const double f = safe_value(M::stage_cost(x, u, t, P));
       const double f_minus = safe_value(M::stage_cost(x, um, t, P));
-      D[L::oLuu + i * NU + i] = (f_plus - 2 * f + f_minus) / (eps * eps);
+      D[L::oLuu + i * NU + i] = div_by(f_plus - 2 * f + f_minus, make_inv_div(eps * eps));
     }
     MAS_UNROLL for (int i = 0; i < NU; ++i) {
       MAS_UNROLL for (int j = 0; j < NU; ++j) {
@@ -143,7 +143,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
           perturb2<NU>(u, i, +eps, j, -eps, up); const double f_pm = safe_value(M::stage_cost(x, up, t, P));
           perturb2<NU>(u, i, -eps, j, +eps, up); const double f_mp = safe_value(M::stage_cost(x, up, t, P));
           perturb2<NU>(u, i, -eps, j, -eps, up); const double f_mm = safe_value(M::stage_cost(x, up, t, P));
-          D[L::oLuu + j * NU + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+          D[L::oLuu + j * NU + i] = div_by(f_pp - f_pm - f_mp + f_mm, make_inv_div(4 * eps * eps));
         }
       }
     }
@@ -160,7 +160,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
         const double f_pm = safe_value(M::stage_cost(xm, up, t, P));
         const double f_mp = safe_value(M::stage_cost(xp, um, t, P));
         const double f_mm = safe_value(M::stage_cost(xm, um, t, P));
-        D[L::oLux + j * NU + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+        D[L::oLux + j * NU + i] = div_by(f_pp - f_pm - f_mp + f_mm, make_inv_div(4 * eps * eps));
       }
     }
   }
@@ -172,12 +172,12 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     MAS_UNROLL for (int i = 0; i < NX; ++i) {
       perturb1<NX>(x, i, +eps, xp); M::equality(xp, u, cp, P);
       perturb1<NX>(x, i, -eps, xm); M::equality(xm, u, cm, P);
-      MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJx + i * M::NEQ + r] = (cp[r] - cm[r]) / (2 * eps);
+      MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJx + i * M::NEQ + r] = div_by(cp[r] - cm[r], make_inv_div(2 * eps));
     }
     MAS_UNROLL for (int i = 0; i < NU; ++i) {
       perturb1<NU>(u, i, +eps, up); M::equality(x, up, cp, P);
       perturb1<NU>(u, i, -eps, um); M::equality(x, um, cm, P);
-      MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJu + i * M::NEQ + r] = (cp[r] - cm[r]) / (2 * eps);
+      MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJu + i * M::NEQ + r] = div_by(cp[r] - cm[r], make_inv_div(2 * eps));
     }
   }
   if constexpr (M::NIN > 0) {
@@ -187,12 +187,12 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     MAS_UNROLL for (int i = 0; i < NX; ++i) {
       perturb1<NX>(x, i, +eps, xp); M::inequality(xp, u, cp, P);
       perturb1<NX>(x, i, -eps, xm); M::inequality(xm, u, cm, P);
-      MAS_UNROLL for (int r = 0; r < M::NIN; ++r) D[L::oInJx + i * M::NIN + r] = (cp[r] - cm[r]) / (2 * eps);
+      MAS_UNROLL for (int r = 0; r < M::NIN; ++r) D[L::oInJx + i * M::NIN + r] = div_by(cp[r] - cm[r], make_inv_div(2 * eps));
     }
     MAS_UNROLL for (int i = 0; i < NU; ++i) {
       perturb1<NU>(u, i, +eps, up); M::inequality(x, up, cp, P);
       perturb1<NU>(u, i, -eps, um); M::inequality(x, um, cm, P);
-      MAS_UNROLL for (int r = 0; r < M::NIN; ++r) D[L::oInJu + i * M::NIN + r] = (cp[r] - cm[r]) / (2 * eps);
+      MAS_UNROLL for (int r = 0; r < M::NIN; ++r) D[L::oInJu + i * M::NIN + r] = div_by(cp[r] - cm[r], make_inv_div(2 * eps));
     }
   }
 }
@@ -225,7 +225,7 @@ MAS_HD void terminal_boundary(const double* xT, double* vx, double* vxx, const M
       const double eps = 1e-6;
       MAS_UNROLL for (int i = 0; i < NX; ++i) {
         perturb1<NX>(xT, i, +eps, xp); perturb1<NX>(xT, i, -eps, xm);
-        vx[i] = (M::terminal_cost(xp, P) - M::terminal_cost(xm, P)) / (2 * eps);
+        vx[i] = div_by(M::terminal_cost(xp, P) - M::terminal_cost(xm, P), make_inv_div(2 * eps));
       }
     }
     {                                                   // :226-261
@@ -235,7 +235,7 @@ MAS_HD void terminal_boundary(const double* xT, double* vx, double* vxx, const M
         const double f_plus = safe_value(M::terminal_cost(xp, P));
         const double f = safe_value(M::terminal_cost(xT, P));
         const double f_minus = safe_value(M::terminal_cost(xm, P));
-        vxx[i * NX + i] = (f_plus - 2 * f + f_minus) / (eps * eps);
+        vxx[i * NX + i] = div_by(f_plus - 2 * f + f_minus, make_inv_div(eps * eps));
       }
       MAS_UNROLL for (int i = 0; i < NX; ++i) {
         MAS_UNROLL for (int j = 0; j < NX; ++j) {
@@ -244,7 +244,7 @@ MAS_HD void terminal_boundary(const double* xT, double* vx, double* vxx, const M
             perturb2<NX>(xT, i, +eps, j, -eps, xp); const double f_pm = safe_value(M::terminal_cost(xp, P));
             perturb2<NX>(xT, i, -eps, j, +eps, xp); const double f_mp = safe_value(M::terminal_cost(xp, P));
             perturb2<NX>(xT, i, -eps, j, -eps, xp); const double f_mm = safe_value(M::terminal_cost(xp, P));
-            vxx[j * NX + i] = (f_pp - f_pm - f_mp + f_mm) / (4 * eps * eps);
+            vxx[j * NX + i] = div_by(f_pp - f_pm - f_mp + f_mm, make_inv_div(4 * eps * eps));
           }
         }
       }

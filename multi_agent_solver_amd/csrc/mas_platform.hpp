@@ -43,3 +43,27 @@ constexpr double kTicksPerMs = 1e5;
 #define MAS_OPAQUE32(v) ((void)0)
 #define MAS_VGPR64(v) ((void)0)
 #endif
+
+// Division by a value that stays the same for a whole kernel (a finite-difference step 2 eps, eps^2, 4 eps^2; a wheelbase).
+// The compiler's IEEE division is eleven dependent instructions (scale, reciprocal seed, two Newton steps, quotient, residual,
+// correction, fix-up); with the divisor's correctly rounded reciprocal y = RN(1 / b) formed once -- at compile time for the
+// finite-difference constants -- the quotient needs only its last three steps,
+//     q = RN(p y),   r = p - b q  (exact in one fma),   RN(q + r y) = RN(p / b)
+// (Markstein's correction step: q is within one ulp of p / b, so r is exact and the fused correction rounds the true quotient
+// perturbed by less than 2^-53 ulp -- the same last step v_div_fmas_f64 takes in the compiler's own expansion), followed by the
+// hardware's v_div_fixup_f64 for the special operands (zero, infinity, NaN).  Bit-identical to `/` wherever quotient and residual
+// stay clear of the subnormal range (|p / b| >= 2^-960 or p == 0) -- checked against the device's own division on 10^9 random
+// operands by tests/hip/div_by_check.hip, and by every parity test against the CPU oracle, which divides with `/`.
+// The CPU builds (oracle, host emulation) use `/`.
+struct InvDiv { double b, y; };
+MAS_HD constexpr InvDiv make_inv_div(double b) { return InvDiv{b, 1.0 / b}; }
+MAS_HD double div_by(double p, const InvDiv& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q = p * d.y;
+  const double r = __builtin_fma(-q, d.b, p);
+  return __builtin_amdgcn_div_fixup(__builtin_fma(r, d.y, q), d.b, p);
+#else
+  return p / d.b;
+#endif
+}
+

@@ -9,6 +9,7 @@ np.array_equal on costs, trajectories and iteration counts; the only exception i
 merit, which the GPU sums agent-major and the oracle step-major (1e-12 relative).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ import pytest
 from conftest import run_batch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -409,3 +411,15 @@ def test_maximum_sizes(gpu_lib, oracle):
     assert np.array_equal(e["cost"][sample], o["cost"]) and np.array_equal(e["X"][sample], o["X"]) and np.array_equal(e["U"][sample], o["U"])
     assert e["iters"][sample].tolist() == o["iters"].tolist()
     assert np.isfinite(e["cost"]).all() and (np.abs(e["U"]) <= 0.5).all() and e["stats"]["agent_iterations"] == int(e["iters"].sum())
+
+
+@pytest.mark.gpu
+def test_division_by_an_invariant_divisor_is_the_ieee_quotient():
+    """div_by (mas_platform.hpp): q = p*y, r = fma(-q, b, p), fma(r, y, q), v_div_fixup -- against the device's own IEEE
+    division, bit for bit, on 2 x 10 million random numerators per divisor (the finite-difference steps, the wheelbase, random
+    ones) and the special values.  tests/hip/div_by_check.hip"""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "hip", "build", "div_by_check")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe, "10"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout, r.stderr[-500:])
