@@ -96,9 +96,9 @@ MAS_DT_FN double mas_dt_kcos(double x, double y) {
  * reproducible, answer.  The functions are branch-free so that a compiler can merge identical
  * sub-expressions across the many perturbed evaluations of a finite-difference sweep, and they are written
  * for a machine on which every instruction of a dependent chain costs the same (a lone GPU wavefront):
- *  - an out-of-range argument is reduced as 0 (so the quadrant arithmetic stays defined) and turns the
- *    reduced argument into NaN by ADDING a poison term, -0.0 for an argument in range -- y + (-0.0) is y bit for
- *    bit, for every y including both zeros -- so no result needs a select of its own;
+ *  - an out-of-range argument turns the reduced argument into NaN by ADDING a poison term, -0.0 for an argument in
+ *    range -- y + (-0.0) is y bit for bit, for every y including both zeros -- so no result needs a select of its
+ *    own (its quadrant, taken from a conversion that saturates, only picks the sign and payload of that NaN);
  *  - a quadrant's sign change is an exclusive-or on the sign bit (what negation is), driven by integer
  *    arithmetic on n instead of compare-and-select. */
 MAS_DT_FN int mas_dt_in_range(double x) { return fabs(x) <= MAS_DT_MAX_ARG; } /* false for NaN */
@@ -114,7 +114,7 @@ MAS_DT_FN double mas_dt_flip_sign(double v, unsigned flip /* bit 0 */) {
 /* reduction shared by all entry points: quadrant n, reduced argument y0 (NaN when x is out of range), tail y1 */
 MAS_DT_FN unsigned mas_dt_reduce(double x, double* y0, double* y1) {
   const int ok = mas_dt_in_range(x);
-  const unsigned n = (unsigned)mas_dt_rem_pio2(ok ? x : 0.0, y0, y1);
+  const unsigned n = (unsigned)mas_dt_rem_pio2(x, y0, y1);   /* out of range: a meaningless reduction (and quadrant) of a result that is NaN anyway */
   *y0 += ok ? -0.0 : (double)NAN;
   return n;
 }

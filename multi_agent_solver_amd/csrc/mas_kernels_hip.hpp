@@ -714,6 +714,18 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
 //   pass 2   q_xx(i,j), q_ux(i,j) [i < NU], q_uu(i,j) [i, j < NU]
 //   pass 3   as in the tile kernel
 // Every output element is the same sequence of multiplies and adds as in the tile kernel and in BackwardBody.
+// sum of N terms in index order, starting FROM THE FIRST TERM -- as Eigen's redux does for the reference's small products.  The
+// CPU oracle and the one-lane bodies start from +0.0 (s = 0.0; s += term_k); the two agree in every bit except that an
+// all-zero sum can come out as -0.0 here and +0.0 there.  No operation of the path tells the two zeros apart (it never
+// divides by, takes the square root or the sign of such a value: LLT rejects a pivot <= 0 before its sqrt), so every result the
+// ABI returns is the same IEEE value; per backward step this is 26 dependent additions less.
+template <int N, class F>
+__device__ __forceinline__ double sum_terms(F term) {
+  double s = term(0);
+  MAS_UNROLL for (int k = 1; k < N; ++k) s += term(k);
+  return s;
+}
+
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
   return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
@@ -840,15 +852,15 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
       const double Vc[NX] = {quad_bcast<0>(Vown), quad_bcast<1>(Vown), quad_bcast<2>(Vown), quad_bcast<3>(Vown)};   // V(k, j)
       const double vxk[NX] = {row_bcast<0>(vxi), row_bcast<1>(vxi), row_bcast<2>(vxi), row_bcast<3>(vxi)};         // v_x(k)
       double s;
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Ai[k] * Vc[k];
+      s = sum_terms<NX>([&](int k) { return Ai[k] * Vc[k]; });
       T[w_atv] = s;
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Bi[k] * Vc[k];
+      s = sum_terms<NX>([&](int k) { return Bi[k] * Vc[k]; });
       T[w_btv] = s;
       if constexpr (!kMerged) {
-        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Ai[k] * vxk[k];
+        s = sum_terms<NX>([&](int k) { return Ai[k] * vxk[k]; });
         qx_i = c.lx + s;
       }
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += Bi[k] * vxk[k];
+      s = sum_terms<NX>([&](int k) { return Bi[k] * vxk[k]; });
       qu_own = c.lu + s;
     }
     wave_sync();
@@ -858,19 +870,19 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
       double ra[NX], rb[NX];
       MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
       double s;
-      s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += ra[k] * Aj[k];
+      s = sum_terms<NX>([&](int k) { return ra[k] * Aj[k]; });
       qxx_own = c.lxx + s;
       T[oQxx + lane] = qxx_own;
       if constexpr (kMerged) {
-        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Bj[k];          // this lane's second-round item (see kMerged)
+        s = sum_terms<NX>([&](int k) { return rb[k] * Bj[k]; });          // this lane's second-round item (see kMerged)
         const double item = c.lux + s;
         T[w_qux] = item;
         row_gather_block_at<NU, 2>(item, quu, std::make_integer_sequence<int, NU * NU>{});   // q_uu(m, n) from lane (2 + m, n)
         quad_gather(item, quxj, std::make_integer_sequence<int, NU>{});
       } else {
-        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Aj[k];
+        s = sum_terms<NX>([&](int k) { return rb[k] * Aj[k]; });
         const double qux_own = c.lux + s;
-        s = 0.0; MAS_UNROLL for (int k = 0; k < NX; ++k) s += rb[k] * Bj[k];
+        s = sum_terms<NX>([&](int k) { return rb[k] * Bj[k]; });
         const double quu_own = c.luu + s;
         T[w_qux] = qux_own;
         row_gather_block_at<NU, 0>(quu_own, quu, std::make_integer_sequence<int, NU * NU>{});
@@ -966,11 +978,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
       }
       llt_solve_identity<NU>(Lfac, ninv);
       MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];
-      MAS_UNROLL for (int m = 0; m < NU; ++m) {
-        double s = 0.0;
-        MAS_UNROLL for (int q = 0; q < NU; ++q) s += ninv[q * NU + m] * qu[q];
-        kf[m] = s;
-      }
+      MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qu[q]; });
       MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
       {
         double quxi[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
@@ -978,35 +986,33 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
         const double qxx_mir = T[oQxx + j + 4 * i];
         if constexpr (kMerged) qx_i = T[oQx + i];
         MAS_UNROLL for (int m = 0; m < NU; ++m) {
-          double si = 0.0, sj = 0.0;
-          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += ninv[q * NU + m] * quxi[q]; sj += ninv[q * NU + m] * quxj[q]; }
-          Ki[m] = si; Kj[m] = sj;
+          Ki[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxi[q]; });
+          Kj[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxj[q]; });
         }
         MAS_UNROLL for (int m = 0; m < NU; ++m) {
-          double si = 0.0, sj = 0.0;
-          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += Ki[q] * quu[m * NU + q]; sj += Kj[q] * quu[m * NU + q]; }
-          ktqi[m] = si; ktqj[m] = sj;
+          ktqi[m] = sum_terms<NU>([&](int q) { return Ki[q] * quu[m * NU + q]; });
+          ktqj[m] = sum_terms<NU>([&](int q) { return Kj[q] * quu[m * NU + q]; });
         }
         double s, own, mir;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * quxj[m];
+        s = sum_terms<NU>([&](int m) { return Ki[m] * quxj[m]; });
         own = qxx_own + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * Kj[m];
+        s = sum_terms<NU>([&](int m) { return quxi[m] * Kj[m]; });
         own = own + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * Kj[m];
+        s = sum_terms<NU>([&](int m) { return ktqi[m] * Kj[m]; });
         own = own + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Kj[m] * quxi[m];
+        s = sum_terms<NU>([&](int m) { return Kj[m] * quxi[m]; });
         mir = qxx_mir + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxj[m] * Ki[m];
+        s = sum_terms<NU>([&](int m) { return quxj[m] * Ki[m]; });
         mir = mir + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqj[m] * Ki[m];
+        s = sum_terms<NU>([&](int m) { return ktqj[m] * Ki[m]; });
         mir = mir + s;
         Vown = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));      // aliased in-place symmetrisation, :192
         double vx_new;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * qu[m];
+        s = sum_terms<NU>([&](int m) { return Ki[m] * qu[m]; });
         vx_new = qx_i + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * kf[m];
+        s = sum_terms<NU>([&](int m) { return quxi[m] * kf[m]; });
         vx_new = vx_new + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
+        s = sum_terms<NU>([&](int m) { return ktqi[m] * kf[m]; });
         vxi = vx_new + s;
         if constexpr (kMerged) T[w_vx] = vxi;                       // pass 2 of the next step reads v_x as an LDS row
         MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[m], Ki[m]);
