@@ -285,6 +285,47 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
   if (act && s == 0) f.trial_merit[static_cast<size_t>(j) * d.Np + a] = c;
 }
 
+// integrate_horizon + objective (RolloutCostBody) with four lanes per agent: the rollout every solve starts from (restore,
+// initialize_problem) is one 64-agents-per-wavefront chain of T steps -- at 4096 agents 64 wavefronts on 1024 SIMDs.
+// lane (agent, s): RK4 stage s; lane s stores state component s (16 consecutive agents = one 128-byte line per row).
+template <class M>
+__global__ void __launch_bounds__(256) mas_rollout_quad_kernel(const RolloutCostBody<M> f) {
+  constexpr int NX = M::NX, NU = M::NU;
+  static_assert(NX == 4, "one state component per lane of the quad");
+  const Dims d = f.d;
+  const int tid = static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x), s = tid & 3;
+  const int a_raw = tid >> 2;
+  if ((a_raw & ~15) >= d.N) return;                                   // wave-uniform: 16 agents per wavefront
+  const bool act = a_raw < d.N;
+  const int a = act ? a_raw : d.N - 1;                                // a surplus quad repeats the last agent (its stores rewrite the same values)
+  unsigned offx[NX], offu[NU];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) offx[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int i = 0; i < NU; ++i) offu[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const unsigned sto_x = static_cast<unsigned>((static_cast<size_t>(s) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np;
+  const double* Ut = f.U; double* Xt = f.X;
+  double x[NX], xn[NX], uA[NU], uB[NU];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = ld_off(f.x0, offx[i]);
+  auto own = [&](const double* v) { const double lo2 = (s & 1) ? v[1] : v[0], hi2 = (s & 1) ? v[3] : v[2]; return (s & 2) ? hi2 : lo2; };
+  st_off(Xt, sto_x, own(x));
+  MAS_UNROLL for (int i = 0; i < NU; ++i) uA[i] = ld_off(Ut, offu[i]);
+  double c = 0.0;
+  auto step = [&](int t, const double* u, double* un) {
+    if (t + 1 < d.T) Ut += sU;                                        // uniform
+    MAS_UNROLL for (int i = 0; i < NU; ++i) { MAS_OPAQUE32(offu[i]); un[i] = ld_off(Ut, offu[i]); }
+    c += M::stage_cost(x, u, t, f.P);
+    QuadRk4<M>::step(x, u, f.dt, s, xn, f.P);
+    Xt += sX;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xt, o, own(x)); }
+  };
+  int t = 0;
+  for (; t + 1 < d.T; t += 2) { step(t, uA, uB); step(t + 1, uB, uA); }
+  if (t < d.T) step(t, uA, uB);
+  c += M::terminal_cost(x, f.P);
+  if (act && s == 0) { f.cost[a] = c; if (f.merit) f.merit[a] = c; }
+}
+
 // ---------------------------------------------------------------- backward, 16 lanes/agent --
 template <class M>
 struct BackwardTileLayout {

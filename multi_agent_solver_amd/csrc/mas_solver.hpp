@@ -165,9 +165,24 @@ class SolverImpl final : public SolverBase {
     }
     initialized = false; rollout_consistent = false;
   }
+  // integrate_horizon + objective of every agent: four lanes per agent where the dynamics allow it (mas_rollout_quad_kernel)
+  void launch_rollout_cost() {
+    const RolloutCostBody<M> body{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)};
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (M::kQuadRk4 && !kConstrained) {
+      if (quad_forward_max_slots() > 0) {
+        be.begin("rollout_cost", 0.0);
+        be.launch_kernel(mas_rollout_quad_kernel<M>, dim3(static_cast<unsigned>((static_cast<size_t>(d.N) * 4 + 255) / 256)), dim3(256), body);
+        be.end();
+        return;
+      }
+    }
+#endif
+    be.template launch_1d<1>("rollout_cost", body, d.N);
+  }
   void initialize_problem() override {
     require(have_x0, "initial states not set");
-    be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
+    launch_rollout_cost();
     if (!radii) radii = dalloc(d.Np);
     initialized = true; rollout_consistent = true;
   }
@@ -653,7 +668,7 @@ class SolverImpl final : public SolverBase {
                                                            counters, 2 * kCounterRing, live_lists[0], live_count0, d.N,
                                                            solves_left, n_solves - 1, timed ? solve_start : nullptr}, d.N);
     if (!rollout_consistent) {
-      be.template launch_1d<1>("rollout_cost", RolloutCostBody<M>{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)}, d.N);
+      launch_rollout_cost();
       rollout_consistent = true;
     }
     stats.solves += static_cast<long long>(d.N) * n_solves;

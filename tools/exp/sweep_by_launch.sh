@@ -10,7 +10,7 @@ rows=[]
 for f in glob.glob("gpurun_out/bylaunch_$W/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
-        k="sweep" if "sweep" in n else "backward" if "backward_tile" in n else "forward" if "ForwardBody" in n else "commit" if "CommitBody" in n else "select" if "SelectBody" in n else None
+        k="sweep" if "sweep" in n else "backward" if "backward_" in n else "forward" if ("ForwardBody" in n or "forward_quad" in n) else "commit" if "CommitBody" in n else "select" if "SelectBody" in n else None
         if k: rows.append((int(r["Start_Timestamp"]), k, (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3, int(r["Grid_Size_X"])))
 rows.sort()
 import collections
