@@ -207,11 +207,50 @@ struct QuadRk4<SingleTrack> {
   }
 };
 template <> struct QuadRk4<SingleTrackLane> : QuadRk4<SingleTrack> {};
+// bicycle6 (mas_models.hpp): steering angle and acceleration are states driven by the controls, so a, delta, v and psi of every
+// stage follow from x and u without sin/cos -- and here tan(delta_s) differs from stage to stage too: the four tan AND the four
+// sin/cos evaluations of a step run side by side.
+template <>
+struct QuadRk4<Bicycle6> {
+  __device__ static void step(const double* x, const double* u, double dt, int s, double* out, const ModelParams& P) {
+    const double L = P.p[6];
+    const double h = (s == 3) ? dt : (0.5 * dt);
+    const double ha = x[5] + h * u[1], hd = x[4] + h * u[0];
+    const double as = (s == 0) ? x[5] : ha;                             // stage state: a, delta
+    const double ds = (s == 0) ? x[4] : hd;
+    const double hv = x[3] + h * quad_from_prev(as);                    // v + h * (dv/dt of the stage below) = v + h * a_{s-1}
+    const double vs = (s == 0) ? x[3] : hv;
+    const double kpsi = div_by(vs * mas_dt_tan(ds), make_inv_div(L));   // dynamics: d[2]
+    const double hp = x[2] + h * quad_from_prev(kpsi);
+    const double psis = (s == 0) ? x[2] : hp;
+    double sn, cs;
+    mas_dt_sincos(psis, &sn, &cs);
+    const double kx = vs * cs, ky = vs * sn;
+    const double k1x = quad_bcast<0>(kx), k2x = quad_bcast<1>(kx), k3x = quad_bcast<2>(kx), k4x = quad_bcast<3>(kx);
+    const double k1y = quad_bcast<0>(ky), k2y = quad_bcast<1>(ky), k3y = quad_bcast<2>(ky), k4y = quad_bcast<3>(ky);
+    const double k1p = quad_bcast<0>(kpsi), k2p = quad_bcast<1>(kpsi), k3p = quad_bcast<2>(kpsi), k4p = quad_bcast<3>(kpsi);
+    const double k1v = quad_bcast<0>(as), k2v = quad_bcast<1>(as), k3v = quad_bcast<2>(as), k4v = quad_bcast<3>(as);
+    out[0] = x[0] + (dt / 6.0) * (((k1x + 2.0 * k2x) + 2.0 * k3x) + k4x);
+    out[1] = x[1] + (dt / 6.0) * (((k1y + 2.0 * k2y) + 2.0 * k3y) + k4y);
+    out[2] = x[2] + (dt / 6.0) * (((k1p + 2.0 * k2p) + 2.0 * k3p) + k4p);
+    out[3] = x[3] + (dt / 6.0) * (((k1v + 2.0 * k2v) + 2.0 * k3v) + k4v);
+    out[4] = x[4] + (dt / 6.0) * (((u[0] + 2.0 * u[0]) + 2.0 * u[0]) + u[0]);
+    out[5] = x[5] + (dt / 6.0) * (((u[1] + 2.0 * u[1]) + 2.0 * u[1]) + u[1]);
+  }
+};
+
+// which state rows a lane of the quad stores: component s, and for NX > 4 also component 4 + (s & 1) (lanes 2, 3 repeat lanes 0, 1)
+template <int NX>
+struct QuadStore {
+  static_assert(NX == 4 || NX == 6, "state components per quad");
+  __device__ static double first(const double* v, int s) { const double lo2 = (s & 1) ? v[1] : v[0], hi2 = (s & 1) ? v[3] : v[2]; return (s & 2) ? hi2 : lo2; }
+  __device__ static double second(const double* v, int s) { if constexpr (NX > 4) return (s & 1) ? v[5] : v[4]; else return 0.0; }
+};
 
 template <class M>
 __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody<M> f, const int* __restrict__ live_list, const int* __restrict__ live_count) {
   constexpr int NX = M::NX, NU = M::NU;
-  static_assert(NX == 4 && NU == 2, "one state component per lane of the quad, one control per lane pair");
+  static_assert((NX == 4 || NX == 6) && NU == 2, "state components per lane of the quad (QuadStore), one control per lane pair");
   const Dims d = f.d;
   const int tid = static_cast<int>(threadIdx.x), s = tid & 3, ci = s & 1;
   const int n_live = live_count ? *live_count : d.N;                   // uniform
@@ -237,6 +276,7 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
   MAS_UNROLL for (int c = 0; c < NX; ++c) offK[c] = static_cast<unsigned>((static_cast<size_t>(c * NU + ci) * d.Np + static_cast<size_t>(a)) * sizeof(double));
   // stores: lane s owns state row s and control row s & 1 of its slot column
   const unsigned sto_x = static_cast<unsigned>((static_cast<size_t>(s) * d.Np + static_cast<size_t>(slot)) * sizeof(double));
+  const unsigned sto_x2 = static_cast<unsigned>((static_cast<size_t>(4 + ci) * d.Np + static_cast<size_t>(slot)) * sizeof(double));   // NX > 4
   const unsigned sto_u = static_cast<unsigned>((static_cast<size_t>(ci) * d.Np + static_cast<size_t>(slot)) * sizeof(double));
   const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np, sK = static_cast<size_t>(NU) * NX * d.Np;
   const double *Xt = f.X, *Ut = f.U, *kt = f.kff, *Kt = f.Kfb;
@@ -251,8 +291,11 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
   };
   double x[NX], xn[NX], u[NU];
   MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = ld_off(f.x0, offx[i]);
-  auto own = [&](const double* v) { const double lo2 = (s & 1) ? v[1] : v[0], hi2 = (s & 1) ? v[3] : v[2]; return (s & 2) ? hi2 : lo2; };
-  st_off(Xjt, sto_x, own(x));
+  auto store_x = [&]() {
+    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xjt, o, QuadStore<NX>::first(x, s)); }
+    if constexpr (NX > 4) { unsigned o = sto_x2; MAS_OPAQUE32(o); st_off(Xjt, o, QuadStore<NX>::second(x, s)); }
+  };
+  store_x();
   request(opA);
   double lbv = f.lb[ci], ubv = f.ub[ci];
   MAS_VGPR64(lbv); MAS_VGPR64(ubv);
@@ -276,7 +319,7 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
     QuadRk4<M>::step(x, u, f.dt, s, xn, f.P);
     Xjt += sX; Ujt += sU;
     MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xjt, o, own(x)); }
+    store_x();
   };
   int t = 0;
   for (; t + 1 < d.T; t += 2) { step(t, opA, opB); step(t + 1, opB, opA); }
@@ -291,7 +334,6 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
 template <class M>
 __global__ void __launch_bounds__(256) mas_rollout_quad_kernel(const RolloutCostBody<M> f) {
   constexpr int NX = M::NX, NU = M::NU;
-  static_assert(NX == 4, "one state component per lane of the quad");
   const Dims d = f.d;
   const int tid = static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x), s = tid & 3;
   const int a_raw = tid >> 2;
@@ -302,12 +344,16 @@ __global__ void __launch_bounds__(256) mas_rollout_quad_kernel(const RolloutCost
   MAS_UNROLL for (int i = 0; i < NX; ++i) offx[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
   MAS_UNROLL for (int i = 0; i < NU; ++i) offu[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
   const unsigned sto_x = static_cast<unsigned>((static_cast<size_t>(s) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const unsigned sto_x2 = static_cast<unsigned>((static_cast<size_t>(4 + (s & 1)) * d.Np + static_cast<size_t>(a)) * sizeof(double));   // NX > 4
   const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np;
   const double* Ut = f.U; double* Xt = f.X;
   double x[NX], xn[NX], uA[NU], uB[NU];
   MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = ld_off(f.x0, offx[i]);
-  auto own = [&](const double* v) { const double lo2 = (s & 1) ? v[1] : v[0], hi2 = (s & 1) ? v[3] : v[2]; return (s & 2) ? hi2 : lo2; };
-  st_off(Xt, sto_x, own(x));
+  auto store_x = [&]() {
+    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xt, o, QuadStore<NX>::first(x, s)); }
+    if constexpr (NX > 4) { unsigned o = sto_x2; MAS_OPAQUE32(o); st_off(Xt, o, QuadStore<NX>::second(x, s)); }
+  };
+  store_x();
   MAS_UNROLL for (int i = 0; i < NU; ++i) uA[i] = ld_off(Ut, offu[i]);
   double c = 0.0;
   auto step = [&](int t, const double* u, double* un) {
@@ -317,13 +363,63 @@ __global__ void __launch_bounds__(256) mas_rollout_quad_kernel(const RolloutCost
     QuadRk4<M>::step(x, u, f.dt, s, xn, f.P);
     Xt += sX;
     MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
-    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xt, o, own(x)); }
+    store_x();
   };
   int t = 0;
   for (; t + 1 < d.T; t += 2) { step(t, uA, uB); step(t + 1, uB, uA); }
   if (t < d.T) step(t, uA, uB);
   c += M::terminal_cost(x, f.P);
   if (act && s == 0) { f.cost[a] = c; if (f.merit) f.merit[a] = c; }
+}
+
+// TrustRerollBody (nash.hpp:219-226: scaled step, rollout, cost) with four lanes per queued agent: the re-roll is a single T-step
+// chain for a handful of agents in most rounds of a chained trust-region run -- pure latency.
+template <class M>
+__global__ void __launch_bounds__(256) mas_trust_reroll_quad_kernel(const TrustRerollBody<M> f) {
+  constexpr int NX = M::NX, NU = M::NU;
+  static_assert(NU == 2, "one control per lane pair");
+  const Dims d = f.d;
+  const int tid = static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x), s = tid & 3, ci = s & 1;
+  const int n_roll = *f.roll_count;                                    // uniform
+  const int slot_raw = tid >> 2;
+  if ((slot_raw & ~15) >= n_roll) return;                              // wave-uniform
+  const bool act = slot_raw < n_roll;
+  const int a = f.roll_list[act ? slot_raw : (slot_raw & ~15)];        // a surplus quad repeats the wavefront's first agent (same values to the same addresses)
+  const double sc = f.scale[a];
+  unsigned offx[NX];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) offx[i] = static_cast<unsigned>((static_cast<size_t>(i) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const unsigned offu = static_cast<unsigned>((static_cast<size_t>(ci) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const unsigned sto_x = static_cast<unsigned>((static_cast<size_t>(s) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const unsigned sto_x2 = static_cast<unsigned>((static_cast<size_t>(4 + ci) * d.Np + static_cast<size_t>(a)) * sizeof(double));   // NX > 4
+  const size_t sX = static_cast<size_t>(NX) * d.Np, sU = static_cast<size_t>(NU) * d.Np;
+  double* Ut = f.U; const double* Uo = f.U_old; double* Xt = f.X;
+  double x[NX], xn[NX], u[NU];
+  MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = ld_off(f.x0, offx[i]);
+  auto store_x = [&]() {
+    { unsigned o = sto_x; MAS_OPAQUE32(o); st_off(Xt, o, QuadStore<NX>::first(x, s)); }
+    if constexpr (NX > 4) { unsigned o = sto_x2; MAS_OPAQUE32(o); st_off(Xt, o, QuadStore<NX>::second(x, s)); }
+  };
+  store_x();
+  double curA = ld_off(Ut, offu), oldA = ld_off(Uo, offu), curB, oldB;
+  double c = 0.0;
+  auto step = [&](int t, double ucur, double uold, double& ncur, double& nold) {
+    double* Uthis = Ut;
+    if (t + 1 < d.T) { Ut += sU; Uo += sU; }                           // uniform
+    { unsigned o = offu; MAS_OPAQUE32(o); ncur = ld_off(Ut, o); nold = ld_off(Uo, o); }
+    const double ui = uold + sc * (ucur - uold);                        // cand_u = old_u + scale * delta, control ci on this lane
+    { unsigned o = offu; MAS_OPAQUE32(o); st_off(Uthis, o, ui); }
+    u[0] = quad_bcast<0>(ui); u[1] = quad_bcast<1>(ui);
+    c += M::stage_cost(x, u, t, f.P);
+    QuadRk4<M>::step(x, u, f.dt, s, xn, f.P);
+    Xt += sX;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    store_x();
+  };
+  int t = 0;
+  for (; t + 1 < d.T; t += 2) { step(t, curA, oldA, curB, oldB); step(t + 1, curB, oldB, curA, oldA); }
+  if (t < d.T) step(t, curA, oldA, curB, oldB);
+  c += M::terminal_cost(x, f.P);
+  if (act && s == 0) f.ts.finish(a, c, f.ts.radii[a]);
 }
 
 // ---------------------------------------------------------------- backward, 16 lanes/agent --

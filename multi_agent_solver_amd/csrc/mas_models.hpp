@@ -233,6 +233,7 @@ struct Bicycle6 : NoConstraints {
                         kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
   static constexpr bool kZeroTerminal = true;
   static constexpr bool kDefaultBounds = true;
+  static constexpr bool kQuadRk4 = true;        // a, delta, v, psi of every RK4 stage follow from x and u without sin/cos
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
 
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {

@@ -180,6 +180,19 @@ class SolverImpl final : public SolverBase {
 #endif
     be.template launch_1d<1>("rollout_cost", body, d.N);
   }
+  void launch_trust_reroll(const TrustRerollBody<M>& body) {
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (M::kQuadRk4 && !kConstrained) {
+      if (quad_forward_max_slots() > 0) {
+        be.begin("trust_reroll", 0.0);
+        be.launch_kernel(mas_trust_reroll_quad_kernel<M>, dim3(static_cast<unsigned>((static_cast<size_t>(d.N) * 4 + 255) / 256)), dim3(256), body);
+        be.end();
+        return;
+      }
+    }
+#endif
+    be.template launch_1d<1>("trust_reroll", body, d.N);
+  }
   void initialize_problem() override {
     require(have_x0, "initial states not set");
     launch_rollout_cost();
@@ -718,7 +731,7 @@ class SolverImpl final : public SolverBase {
       if (trust_epilogue) {
         const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
         be.template launch_1d<1>("trust_norm", TrustNormBody<M>{d, trust_ended, U, U_old, ts, trust_scale, trust_roll_list, trust_roll_count}, d.N);
-        be.template launch_1d<1>("trust_reroll", TrustRerollBody<M>{d, dt, P, x0, X, U, U_old, trust_scale, ts, trust_roll_list, trust_roll_count}, d.N);
+        launch_trust_reroll(TrustRerollBody<M>{d, dt, P, x0, X, U, U_old, trust_scale, ts, trust_roll_list, trust_roll_count});
         be.template launch_2d<4>("trust_copy", TrustCopyBody<M>{d, trust_verdict, X, U, X_old, U_old, trust_roll_count}, d.N, d.T + 1);
       }
       if constexpr (kConstrained) {
