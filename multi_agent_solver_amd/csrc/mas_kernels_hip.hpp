@@ -422,6 +422,18 @@ __global__ void __launch_bounds__(256) mas_trust_reroll_quad_kernel(const TrustR
   if (act && s == 0) f.ts.finish(a, c, f.ts.radii[a]);
 }
 
+// sum of N terms in index order, starting FROM THE FIRST TERM -- as Eigen's redux does for the reference's small products.  The
+// CPU oracle and the one-lane bodies start from +0.0 (s = 0.0; s += term_k); the two agree in every bit except that an
+// all-zero sum can come out as -0.0 here and +0.0 there.  No operation of the path tells the two zeros apart (it never
+// divides by, takes the square root or the sign of such a value: LLT rejects a pivot <= 0 before its sqrt), so every result the
+// ABI returns is the same IEEE value; per backward step of the (4, 2) models this is 26 dependent additions less.
+template <int N, class F>
+__device__ __forceinline__ double sum_terms(F term) {
+  double s = term(0);
+  MAS_UNROLL for (int k = 1; k < N; ++k) s += term(k);
+  return s;
+}
+
 // ---------------------------------------------------------------- backward, 16 lanes/agent --
 template <class M>
 struct BackwardTileLayout {
@@ -634,8 +646,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     {
       double res[R1];
       MAS_UNROLL for (int r = 0; r < R1; ++r) {
-        double s = 0.0;
-        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p1[r] + k] * T[q1[r] + k];
+        const double s = sum_terms<NX>([&](int k) { return T[p1[r] + k] * T[q1[r] + k]; });
         res[r] = T[b1[r]] + s;                                        // items without a bias term add -0.0
       }
       MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // idle lanes write their own pad slot
@@ -654,8 +665,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     {
       double res[R2];
       MAS_UNROLL for (int r = 0; r < R2; ++r) {
-        double s = 0.0;
-        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[p2[r] + k * ps2[r]] * T[q2[r] + k];
+        const double s = sum_terms<NX>([&](int k) { return T[p2[r] + k * ps2[r]] * T[q2[r] + k]; });
         res[r] = T[b2[r]] + s;
       }
       MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
@@ -764,11 +774,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
       MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
       llt_solve_identity<NU>(Lfac, ninv);                           // Quu_reg^-1, :183
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) ninv[i] = -ninv[i];
-      MAS_UNROLL for (int m = 0; m < NU; ++m) {                     // k = -Quu^-1 q_u, :185
-        double s = 0.0;
-        MAS_UNROLL for (int q = 0; q < NU; ++q) s += ninv[q * NU + m] * qu[q];
-        kf[m] = s;
-      }
+      MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qu[q]; });   // k = -Quu^-1 q_u, :185
       // gain stores are unconditional straight-line code: every lane of an agent holds the same k (and every lane
       // with the same i the same K column), so the duplicates write identical bits to identical addresses, and an
       // idle slot writes into the unused gain rows of its retired agent: no divergent branch, no exec juggling.
@@ -784,28 +790,26 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
         MAS_UNROLL for (int m = 0; m < NU; ++m) { quxi[m] = T[TL::oQux + i * NU + m]; quxj[m] = T[TL::oQux + j * NU + m]; }
         const double qxx_own = T[TL::oQxx + j * NX + i], qxx_mir = T[TL::oQxx + i * NX + j], qx_i = T[TL::oQx + i];
         MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // columns i and j of K = -Quu^-1 q_ux, :186
-          double si = 0.0, sj = 0.0;
-          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += ninv[q * NU + m] * quxi[q]; sj += ninv[q * NU + m] * quxj[q]; }
-          Ki[m] = si; Kj[m] = sj;
+          Ki[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxi[q]; });
+          Kj[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxj[q]; });
         }
         MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // rows i and j of K^T q_uu (unregularised)
-          double si = 0.0, sj = 0.0;
-          MAS_UNROLL for (int q = 0; q < NU; ++q) { si += Ki[q] * quu[m * NU + q]; sj += Kj[q] * quu[m * NU + q]; }
-          ktqi[m] = si; ktqj[m] = sj;
+          ktqi[m] = sum_terms<NU>([&](int q) { return Ki[q] * quu[m * NU + q]; });
+          ktqj[m] = sum_terms<NU>([&](int q) { return Kj[q] * quu[m * NU + q]; });
         }
         // own entry (i,j) and mirror entry (j,i) of v_xx, :190-191
         double s, own, mir;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * quxj[m];
+        s = sum_terms<NU>([&](int m) { return Ki[m] * quxj[m]; });
         own = qxx_own + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * Kj[m];
+        s = sum_terms<NU>([&](int m) { return quxi[m] * Kj[m]; });
         own = own + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * Kj[m];
+        s = sum_terms<NU>([&](int m) { return ktqi[m] * Kj[m]; });
         own = own + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Kj[m] * quxi[m];
+        s = sum_terms<NU>([&](int m) { return Kj[m] * quxi[m]; });
         mir = qxx_mir + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxj[m] * Ki[m];
+        s = sum_terms<NU>([&](int m) { return quxj[m] * Ki[m]; });
         mir = mir + s;
-        s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqj[m] * Ki[m];
+        s = sum_terms<NU>([&](int m) { return ktqj[m] * Ki[m]; });
         mir = mir + s;
         // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: a lower or diagonal
         // entry averages the old values, an upper entry sees its (already rewritten) mirror
@@ -814,11 +818,11 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
         // the lanes of the first tile column (j == 0) also own gain column i and v_x entry i, :186,188-189
         {
           double vxi;
-          s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += Ki[m] * qu[m];
+          s = sum_terms<NU>([&](int m) { return Ki[m] * qu[m]; });
           vxi = qx_i + s;
-          s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += quxi[m] * kf[m];
+          s = sum_terms<NU>([&](int m) { return quxi[m] * kf[m]; });
           vxi = vxi + s;
-          s = 0.0; MAS_UNROLL for (int m = 0; m < NU; ++m) s += ktqi[m] * kf[m];
+          s = sum_terms<NU>([&](int m) { return ktqi[m] * kf[m]; });
           vxi = vxi + s;
           const bool owner = live && j == 0;
           T[owner ? (TL::oVx + i) : TL::pad_at(TL::oVx + w)] = vxi;
@@ -851,18 +855,6 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
 //   pass 2   q_xx(i,j), q_ux(i,j) [i < NU], q_uu(i,j) [i, j < NU]
 //   pass 3   as in the tile kernel
 // Every output element is the same sequence of multiplies and adds as in the tile kernel and in BackwardBody.
-// sum of N terms in index order, starting FROM THE FIRST TERM -- as Eigen's redux does for the reference's small products.  The
-// CPU oracle and the one-lane bodies start from +0.0 (s = 0.0; s += term_k); the two agree in every bit except that an
-// all-zero sum can come out as -0.0 here and +0.0 there.  No operation of the path tells the two zeros apart (it never
-// divides by, takes the square root or the sign of such a value: LLT rejects a pivot <= 0 before its sqrt), so every result the
-// ABI returns is the same IEEE value; per backward step this is 26 dependent additions less.
-template <int N, class F>
-__device__ __forceinline__ double sum_terms(F term) {
-  double s = term(0);
-  MAS_UNROLL for (int k = 1; k < N; ++k) s += term(k);
-  return s;
-}
-
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
   return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
