@@ -888,6 +888,11 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   //    i >= 2, j < NU   q_uu(i-2, j)    = l_uu + (B^T V)(i-2, :) . B(:, j)          [i - 2 < NU]
   //    i >= 2, j >= 2   q_x(c)          = l_x  + v_x . A(:, c),  c = (i-2) + 2 (j-2)   (v_x kept in LDS for this)
   constexpr bool kMerged = NU <= 2;
+  // Models whose control Hessian is analytic (the identity LQR: l_uu = 2 I, q_uu positive definite by construction) never climb the
+  // ladder: trying rung 0 on every lane first saves them the rung additions and the exchange of the factor.  With finite-
+  // difference Hessians a quarter of the steps need rungs 5-12 and a wavefront of four agents rarely passes as a whole: measured
+  // on C3 the attempt costs as much as it saves (91.3 -> 93 us), so those models go straight to the 16-rung form.
+  constexpr bool kRung0First = M::kAnalyticLuu && !SharedLadder;
   __shared__ double lds[WPB * APW * STRIDE];
   __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];
   __shared__ unsigned blk_agreed[2];
@@ -1024,10 +1029,20 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
       {
         double cur[NU * NU];
         MAS_UNROLL for (int e = 0; e < NU * NU; ++e) cur[e] = quu[e];
+        int win = -1;
+        bool rung0_everywhere = false;
+        if constexpr (kRung0First) {
+          // every lane factorises q_uu as it is; if that succeeds for every agent of the wavefront -- a wave-uniform outcome --
+          // each lane already HOLDS the winning factor: no rung additions (2 x 15 per diagonal entry), no exchange of NU^2 values
+          MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = cur[e];
+          const int ok0 = llt_compute_straight<NU>(Lfac) == 0;
+          rung0_everywhere = __ballot(ok0 || !valid) == ~0ull;
+          if (rung0_everywhere) win = 0;
+        }
+        if (!rung0_everywhere) {
         MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
           MAS_UNROLL for (int e = 0; e < NU; ++e) cur[e * NU + e] += rung_add[q];
         }
-        int win = -1;
         if constexpr (SharedLadder) {
           double reg_next = 0.0;
           for (int base = 0, chunk = 0;; base += LL, ++chunk) {
@@ -1104,6 +1119,9 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
         if (lane == 0 && (!SharedLadder || a == 0)) regs += win;
         wave_sync();                                                 // also orders the pass-2 outputs before the reads below
         MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+        } else {
+          wave_sync();                                               // the pass-2 outputs before the reads below
+        }
       }
       llt_solve_identity<NU>(Lfac, ninv);
       MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];

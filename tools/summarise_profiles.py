@@ -17,17 +17,18 @@ W, TAG, D = sys.argv[1], sys.argv[2], sys.argv[3]
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
 
-KERNELS = (("sweep", ("mas_sweep_kernel", "SweepBody")), ("central_backward", ("mas_backward_tile_kernel<", "true>")),
-           ("backward", ("mas_backward_tile_kernel", "BackwardBody")), ("forward", ("ForwardBody",)), ("select", ("SelectBody",)),
-           ("commit", ("CommitBody",)), ("trust_region", ("TrustRegion",)), ("rollout_cost", ("RolloutCostBody",)))
+KERNELS = (("sweep", ("mas_sweep_kernel", "SweepBody")), ("central_backward", ()),
+           ("backward", ("mas_backward_tile_kernel", "mas_backward_row_kernel", "BackwardBody")), ("forward", ("ForwardBody",)), ("select", ("SelectBody",)),
+           ("commit", ("CommitBody", "CommitSlotBody")), ("trust_reroll", ("TrustRerollBody",)), ("trust_norm", ("TrustNormBody",)), ("trust_copy", ("TrustCopyBody",)),
+           ("trust_region", ("TrustRegion",)), ("rollout_cost", ("RolloutCostBody",)))
 
 
 def classify(name):
-    if "mas_backward_tile_kernel" in name and ", true" in name.split("(")[0]:      # <Model, 16, true, WPB>: the shared ladder of the centralised strategy
+    head = name.split("(")[0]
+    # <Model, 16, true, WPB> (LDS-tile form) / <Model, true, WPB> (registers + DPP form): the shared ladder of the centralised strategy
+    if ("mas_backward_tile_kernel" in head or "mas_backward_row_kernel" in head) and ", true" in head:
         return "central_backward"
     for key, pats in KERNELS:
-        if key == "central_backward":
-            continue
         if any(p in name for p in pats):
             return key
     return None
