@@ -423,3 +423,28 @@ def test_division_by_an_invariant_divisor_is_the_ieee_quotient():
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     r = subprocess.run([exe, "10"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
+@pytest.mark.parametrize("model,T,dt,strategy,outer", [("MODEL_SINGLE_TRACK", 60, 0.5, "sequential", 4), ("MODEL_SINGLE_TRACK", 40, 0.5, "trustregion", 3),
+                                                       ("MODEL_SINGLE_TRACK", 40, 0.5, "centralized", 1), ("MODEL_LQR_IDENTITY", 30, 0.1, "sequential", 3),
+                                                       ("MODEL_SINGLE_TRACK_LANE", 50, 0.1, "sequential", 2), ("MODEL_BICYCLE6", 80, 0.25, "trustregion", 3)])
+def test_kernel_forms_agree(gpu_lib, oracle, monkeypatch, model, T, dt, strategy, outer):
+    """The second half of round 2 added a second form of three kernels: line search / initial rollout / trust-region re-roll with
+    four lanes per rollout (DPP quads) beside one lane per rollout, and the backward pass in registers + DPP (NX = 4) beside the
+    LDS-tile form.  Which form runs depends on the number of live agents and the model; here the same perturbed problem is
+    solved with the new forms (default: 330 agents are below the four-lane bound from round 0 on) and with the round-1 forms
+    forced by the library's A/B switches -- equal results (and both equal to the oracle)."""
+    mid = getattr(oracle, model)
+    N = 330
+    rng = np.random.default_rng(7)
+    base = {"MODEL_LQR_IDENTITY": lambda: oracle.lqr_x0(N), "MODEL_BICYCLE6": lambda: oracle.bicycle6_x0(N)}.get(model, lambda: oracle.single_track_x0(N))()
+    x0 = base + 0.05 * rng.standard_normal(base.shape)
+    new = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer)
+    monkeypatch.setenv("MAS_HIP_FORWARD_QUAD_MAX", "0")
+    monkeypatch.setenv("MAS_HIP_BACKWARD_TILE", "1")
+    old = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer)
+    for key in ("cost", "X", "U", "iters", "status"):
+        assert np.array_equal(new[key], old[key]), key
+    assert new["stats"]["reg_events"] == old["stats"]["reg_events"]
+    o = oracle.solve_batch(mid, x0, None, T, dt, strategy=strategy, max_outer=outer)
+    _same(new, o, total_exact=(strategy != "centralized"))
