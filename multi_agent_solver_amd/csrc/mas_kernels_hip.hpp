@@ -484,13 +484,18 @@ struct LadderSync {
   int combine = 1;                       // workgroups of several wavefronts: combine their masks through LDS and arrive once per workgroup (measured on C2, us per pass: 245 against 546 when each of the 64 wavefronts arrives itself; single-wavefront workgroups: 253)
   static constexpr int kChunks = 32, kArrivalShift = 32;
 };
-__device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned wave_ok_mask, int n_waves) {
-  unsigned agreed = 0u;
+__device__ inline void ladder_post(const LadderSync& sy, int slot, unsigned wave_ok_mask) {
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* w = sy.words + static_cast<size_t>(slot) * 4;
     const unsigned long long fail = ~wave_ok_mask & 0xFFFFu;
     if (fail != 0ull) __hip_atomic_fetch_or(w, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(w, 1ull << LadderSync::kArrivalShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ inline unsigned ladder_wait(const LadderSync& sy, int slot, int n_waves) {
+  unsigned agreed = 0u;
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* w = sy.words + static_cast<size_t>(slot) * 4;
     unsigned long long v = 0ull;
     int spins = 0;
     for (;;) {
@@ -502,6 +507,10 @@ __device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned
     agreed = static_cast<unsigned>(~v) & 0xFFFFu;
   }
   return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(agreed)));
+}
+__device__ inline unsigned ladder_agree(const LadderSync& sy, int slot, unsigned wave_ok_mask, int n_waves) {
+  ladder_post(sy, slot, wave_ok_mask);
+  return ladder_wait(sy, slot, n_waves);
 }
 
 // WPB = wavefronts per workgroup; the wavefronts of a workgroup are independent (each owns its four LDS tiles) except in the
@@ -1171,6 +1180,272 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   int t = d.T - 1;
   for (; t >= 1; t -= 2) { step(t, tA, tB); step(t - 1, tB, tA); }
   if (t == 0) step(0, tA, tB);
+  if (valid && lane == 0) reg_events[a] += regs;
+}
+
+// ------------------------------------- centralised backward pass, NX == 4: the agreement's latency behind a speculative step --
+// mas_backward_row_kernel<M, true, WPB> does, per time step, 0.9 us of work and then waits ~1.5 us for the rung every agent of the
+// stacked problem agrees on (an arrive-and-wait among the launch's workgroups costs 0.9 us bare, xcd_barrier ubench).  On C2 three
+// steps out of four agree on rung 0 (oracle: 296 of 400).  This kernel therefore posts its rung mask for step t and, if rung 0
+// works for all ITS agents, goes on at once as if rung 0 had been agreed: pass 3 of step t with rung 0, then passes 1-2 and the
+// ladder of step t-1 -- the work of one full step -- and only then reads the agreement of step t.  If it is rung 0 (the common
+// case) the speculative work stands and the mask of step t-1 is posted; otherwise pass 3 of step t and the front of step t-1 are
+// redone with the agreed rung.  Nothing speculative is ever published: a wavefront posts the mask of step t-1 only after step t
+// is settled, so every word of LadderSync is written once per wavefront exactly as in the plain kernel, and the gains of a
+// step are simply stored again when it is redone.  Cost per step ~ max(agreement, work) instead of their sum.
+// A step is split in front(t) = passes 1, 2 + the 16 rung candidates of the ladder (everything that does not depend on the
+// agreed rung of step t) and back(t, rung) = factor exchange + pass 3.  front(t-1) must not destroy what a redo of back(t)
+// reads: its register outputs ping-pong between two sets and its LDS outputs (q_xx, q_ux, q_x) between two regions by parity of t.
+template <class M, int WPB>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2)))   // two Front sets + two tiles in registers: ~250 VGPRs, never more than one wavefront per SIMD anyway
+mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
+                                                                        double* __restrict__ kff, double* __restrict__ Kfb,
+                                                                        long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n,
+                                                                        LadderSync sync) {
+  using L = DerivLayout<M>;
+  constexpr int NX = 4, NU = M::NU, ND = L::ND;
+  static_assert(M::NX == 4 && NU >= 1 && NU <= 4, "one DPP row = the 4 x 4 value Hessian");
+  static_assert(L::oB + NX * NU <= 2 * kTileChunk && ND >= 2 * kTileChunk, "the columns of A and B lie in full-width chunks (16-byte aligned pairs)");
+  constexpr int LPA = 16, APW = 4, LL = 16;
+  // LDS per agent (doubles): as in mas_backward_row_kernel, with the pass-2 outputs twice (parity of t)
+  constexpr int oAtV = 0, oBtV = 16, oR2 = 32, kR2 = 40 /* q_xx 16, q_ux 16, q_x 4 (+4) */, rQxx = 0, rQux = 16, rQx = 32,
+                oL = oR2 + 2 * kR2, oVx = oL + 16, oPad = oVx + 16, STRIDE = 176;
+  static_assert(oPad + 16 <= STRIDE && STRIDE % 32 == 16, "tile stride");
+  constexpr bool kMerged = NU <= 2;
+  __shared__ double lds[WPB * APW * STRIDE];
+  __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];
+  __shared__ unsigned blk_agreed[2];
+  unsigned agreement_parity = 0;
+
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane;
+  const int i = lane & 3, j = lane >> 2, iu = (i < NU) ? i : NU - 1, ju = (j < NU) ? j : NU - 1;
+  const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
+  const bool valid = (a < n) && active[a] != 0;
+  if (active[lo] == 0) return;                               // the stacked solve has ended (all flags fall together): uniform over the whole launch
+  double* T = lds + (wave * APW + slot) * STRIDE;
+  auto wave_sync = [] {
+    if constexpr (WPB == 1) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  if (lane == 0) {                                           // terminal boundary condition, ilqr.hpp:92-102
+    double xT[NX], vx[NX], vxx[NX * NX];
+    MAS_UNROLL for (int q = 0; q < NX; ++q) xT[q] = MAS_AT(X, d.T * NX + q, a);
+    terminal_boundary<M>(xT, vx, vxx, P);
+    MAS_UNROLL for (int q = 0; q < NX; ++q) T[oVx + q] = vx[q];
+    MAS_UNROLL for (int q = 0; q < NX * NX; ++q) T[oR2 + rQxx + q] = vxx[q];
+  }
+  wave_sync();
+  double Vown = T[oR2 + rQxx + lane], vxi = T[oVx + i];
+  wave_sync();
+
+  auto elem_off = [&](int e) {
+    const int c = e / kTileChunk, cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
+    return static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + static_cast<size_t>(e % kTileChunk)) * sizeof(double));
+  };
+  unsigned oAi = elem_off(L::oA + 4 * i), oAj = elem_off(L::oA + 4 * j), oBi = elem_off(L::oB + 4 * iu), oBj = elem_off(L::oB + 4 * ju);
+  unsigned olx = elem_off(L::oLx + i), olu = elem_off(L::oLu + iu), olxx = elem_off(L::oLxx + lane), olux = elem_off(L::oLux + iu + NU * j),
+           oluu = elem_off(L::oLuu + iu + NU * ju);
+  const int item2 = (i < NU) ? 0 : ((i >= 2 && j < NU && i - 2 < NU) ? 1 : ((i >= 2 && j >= 2) ? 2 : 3));   // q_ux, q_uu, q_x, none (see mas_backward_row_kernel)
+  const int c2 = (i - 2) + 2 * (j - 2);
+  int r_row2 = oBtV + iu * 4;
+  if constexpr (kMerged) {
+    if (item2 == 0) { oBj = oAj; }
+    else if (item2 == 1) { oBj = elem_off(L::oB + 4 * j); olux = elem_off(L::oLuu + (i - 2) + NU * j); r_row2 = oBtV + (i - 2) * 4; }
+    else if (item2 == 2) { oBj = elem_off(L::oA + 4 * c2); olux = elem_off(L::oLx + c2); r_row2 = oVx; }
+    else { oBj = oAj; r_row2 = oBtV; }
+  }
+  struct Tile { double2 Ai[2], Aj[2], Bi[2], Bj[2]; double lx, lu, lxx, lux, luu; };
+  const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
+  const double* tiles_0 = D + static_cast<size_t>(__builtin_amdgcn_readfirstlane(a0 / 64)) * 64 * ND;       // this wavefront's block of step 0 (uniform)
+  auto fetch = [&](Tile& o, int t) {
+    const double* tiles_t = tiles_0 + static_cast<size_t>(t) * step_doubles;
+    o.Ai[0] = ld2_off(tiles_t, oAi); o.Ai[1] = ld2_off(tiles_t, oAi + 16);
+    o.Aj[0] = ld2_off(tiles_t, oAj); o.Aj[1] = ld2_off(tiles_t, oAj + 16);
+    o.Bi[0] = ld2_off(tiles_t, oBi); o.Bi[1] = ld2_off(tiles_t, oBi + 16);
+    o.Bj[0] = ld2_off(tiles_t, oBj); o.Bj[1] = ld2_off(tiles_t, oBj + 16);
+    o.lu = ld_off(tiles_t, olu); o.lxx = ld_off(tiles_t, olxx); o.lux = ld_off(tiles_t, olux);
+    if constexpr (!kMerged) { o.lx = ld_off(tiles_t, olx); o.luu = ld_off(tiles_t, oluu); }
+  };
+  long long regs = 0;
+  double rung_add[LL - 1];
+  {
+    double reg = 1e-6;
+    MAS_UNROLL for (int q = 0; q < LL - 1; ++q) { rung_add[q] = (q < rung_lane) ? reg : -0.0; reg *= 10.0; }
+  }
+  unsigned goff[NU], koff[NU];
+  MAS_UNROLL for (int m = 0; m < NU; ++m) goff[m] = static_cast<unsigned>((static_cast<size_t>(m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int m = 0; m < NU; ++m) koff[m] = static_cast<unsigned>((static_cast<size_t>(i * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  const int w_atv = oAtV + i * 4 + j, w_btv = (i < NU) ? (oBtV + i * 4 + j) : (oPad + lane);
+  const int w_qux_rel = (i < NU) ? (rQux + j * NU + i) : ((kMerged && item2 == 2) ? (rQx + c2) : -1);     // relative to the parity's region; -1: pad
+  const int w_vx = (j == 0) ? (oVx + i) : (oPad + lane);
+
+  // what front(t) hands to back(t): this lane's rung candidate (matrix and factor), the broadcast pass-2 results, the mask
+  struct Front { double quu[NU * NU], qu[NU], quxj[NU], qxx_own, qx_i, cur[NU * NU], Lcand[NU * NU]; unsigned field; };
+
+  auto front = [&](const Tile& c, int par, Front& o) {
+    const int R2 = oR2 + par * kR2;
+    const double Ai[NX] = {c.Ai[0].x, c.Ai[0].y, c.Ai[1].x, c.Ai[1].y}, Aj[NX] = {c.Aj[0].x, c.Aj[0].y, c.Aj[1].x, c.Aj[1].y};
+    const double Bi[NX] = {c.Bi[0].x, c.Bi[0].y, c.Bi[1].x, c.Bi[1].y}, Bj[NX] = {c.Bj[0].x, c.Bj[0].y, c.Bj[1].x, c.Bj[1].y};
+    double qu_own;
+    {
+      const double Vc[NX] = {quad_bcast<0>(Vown), quad_bcast<1>(Vown), quad_bcast<2>(Vown), quad_bcast<3>(Vown)};
+      const double vxk[NX] = {row_bcast<0>(vxi), row_bcast<1>(vxi), row_bcast<2>(vxi), row_bcast<3>(vxi)};
+      T[w_atv] = sum_terms<NX>([&](int k) { return Ai[k] * Vc[k]; });
+      T[w_btv] = sum_terms<NX>([&](int k) { return Bi[k] * Vc[k]; });
+      if constexpr (!kMerged) o.qx_i = c.lx + sum_terms<NX>([&](int k) { return Ai[k] * vxk[k]; });
+      qu_own = c.lu + sum_terms<NX>([&](int k) { return Bi[k] * vxk[k]; });
+    }
+    wave_sync();
+    {
+      double ra[NX], rb[NX];
+      MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
+      o.qxx_own = c.lxx + sum_terms<NX>([&](int k) { return ra[k] * Aj[k]; });
+      T[R2 + rQxx + lane] = o.qxx_own;
+      if constexpr (kMerged) {
+        const double item = c.lux + sum_terms<NX>([&](int k) { return rb[k] * Bj[k]; });
+        T[w_qux_rel >= 0 ? R2 + w_qux_rel : oPad + lane] = item;
+        row_gather_block_at<NU, 2>(item, o.quu, std::make_integer_sequence<int, NU * NU>{});
+        quad_gather(item, o.quxj, std::make_integer_sequence<int, NU>{});
+      } else {
+        const double qux_own = c.lux + sum_terms<NX>([&](int k) { return rb[k] * Aj[k]; });
+        const double quu_own = c.luu + sum_terms<NX>([&](int k) { return rb[k] * Bj[k]; });
+        T[w_qux_rel >= 0 ? R2 + w_qux_rel : oPad + lane] = qux_own;
+        row_gather_block_at<NU, 0>(quu_own, o.quu, std::make_integer_sequence<int, NU * NU>{});
+        quad_gather(qux_own, o.quxj, std::make_integer_sequence<int, NU>{});
+      }
+      row_gather_first(qu_own, o.qu, std::make_integer_sequence<int, NU>{});
+    }
+    // the 16 rung candidates of the ladder (ilqr.hpp:172-182), lane r holding rung r
+    MAS_UNROLL for (int e = 0; e < NU * NU; ++e) o.cur[e] = o.quu[e];
+    MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
+      MAS_UNROLL for (int e = 0; e < NU; ++e) o.cur[e * NU + e] += rung_add[q];
+    }
+    MAS_UNROLL for (int e = 0; e < NU * NU; ++e) o.Lcand[e] = o.cur[e];
+    const int ok = llt_compute<NU>(o.Lcand) == 0;
+    unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+    if (!valid) field = 0xFFFFu;
+    MAS_UNROLL for (int sh = LPA; sh < 64; sh <<= 1) field &= static_cast<unsigned>(__shfl_xor(static_cast<int>(field), sh));
+    o.field = field;
+  };
+
+  // pass 3 of step t with the factor of lane `src` (rung src of the current chunk): gains, value function
+  auto back = [&](int t, int par, const Front& f, const double* Lsrc, int src) {
+    const int R2 = oR2 + par * kR2;
+    double Lfac[NU * NU], ninv[NU * NU], kf[NU];
+    if (lane == src) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lsrc[e]; }
+    wave_sync();                                                 // also orders the pass-2 outputs before the reads below
+    MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+    double* kff_t = kff + static_cast<size_t>(t) * NU * d.Np;
+    double* Kfb_t = Kfb + static_cast<size_t>(t) * NU * NX * d.Np;
+    llt_solve_identity<NU>(Lfac, ninv);
+    MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];
+    MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * f.qu[q]; });
+    MAS_UNROLL for (int m = 0; m < NU; ++m) { unsigned o = goff[m]; MAS_OPAQUE32(o); st_off(kff_t, o, kf[m]); }
+    double quxi[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
+    MAS_UNROLL for (int m = 0; m < NU; ++m) quxi[m] = T[R2 + rQux + i * NU + m];
+    const double qxx_mir = T[R2 + rQxx + j + 4 * i];
+    double qx_i = f.qx_i;
+    if constexpr (kMerged) qx_i = T[R2 + rQx + i];
+    MAS_UNROLL for (int m = 0; m < NU; ++m) {
+      Ki[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxi[q]; });
+      Kj[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * f.quxj[q]; });
+    }
+    MAS_UNROLL for (int m = 0; m < NU; ++m) {
+      ktqi[m] = sum_terms<NU>([&](int q) { return Ki[q] * f.quu[m * NU + q]; });
+      ktqj[m] = sum_terms<NU>([&](int q) { return Kj[q] * f.quu[m * NU + q]; });
+    }
+    double own, mir;
+    own = f.qxx_own + sum_terms<NU>([&](int m) { return Ki[m] * f.quxj[m]; });
+    own = own + sum_terms<NU>([&](int m) { return quxi[m] * Kj[m]; });
+    own = own + sum_terms<NU>([&](int m) { return ktqi[m] * Kj[m]; });
+    mir = qxx_mir + sum_terms<NU>([&](int m) { return Kj[m] * quxi[m]; });
+    mir = mir + sum_terms<NU>([&](int m) { return f.quxj[m] * Ki[m]; });
+    mir = mir + sum_terms<NU>([&](int m) { return ktqj[m] * Ki[m]; });
+    Vown = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));      // aliased in-place symmetrisation, :192
+    double vx_new = qx_i + sum_terms<NU>([&](int m) { return Ki[m] * f.qu[m]; });
+    vx_new = vx_new + sum_terms<NU>([&](int m) { return quxi[m] * kf[m]; });
+    vxi = vx_new + sum_terms<NU>([&](int m) { return ktqi[m] * kf[m]; });
+    if constexpr (kMerged) T[w_vx] = vxi;
+    MAS_UNROLL for (int m = 0; m < NU; ++m) { unsigned o = koff[m]; MAS_OPAQUE32(o); st_off(Kfb_t, o, Ki[m]); }
+  };
+
+  // the agreement, split in two: arrive (every wavefront / one per workgroup) and wait
+  const bool one_group = gridDim.x == 1;
+  auto post = [&](int word, unsigned field) {
+    if constexpr (WPB > 1) {
+      if (tid == 0) blk_field[agreement_parity][wave] = field;
+      __syncthreads();
+      if (wave == 0) {
+        unsigned bf = 0xFFFFu;
+        MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[agreement_parity][wv];
+        if (one_group) { if (tid == 0) blk_agreed[agreement_parity] = bf; }
+        else ladder_post(sync, word, bf);
+      }
+    } else {
+      ladder_post(sync, word, field);
+    }
+  };
+  auto wait = [&](int word) -> unsigned {
+    unsigned agreed;
+    if constexpr (WPB > 1) {
+      if (wave == 0 && !one_group) { const unsigned g = ladder_wait(sync, word, static_cast<int>(gridDim.x)); if (tid == 0) blk_agreed[agreement_parity] = g; }
+      __syncthreads();
+      agreed = blk_agreed[agreement_parity];
+      agreement_parity ^= 1u;
+    } else {
+      agreed = ladder_wait(sync, word, static_cast<int>(gridDim.x));
+    }
+    return agreed;
+  };
+  // rungs beyond the first sixteen: all agents move on together, 16 rungs per agreement, synchronously (never on the shipped workloads)
+  auto settle_beyond = [&](int t, Front& f, int& win) {
+    double reg_next = 1e-6;
+    for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0;
+    for (int base = LL, chunk = 1;; base += LL, ++chunk) {
+      for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int e = 0; e < NU; ++e) f.cur[e * NU + e] += reg_next; reg_next *= 10.0; }
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) f.Lcand[e] = f.cur[e];
+      const int ok = llt_compute<NU>(f.Lcand) == 0;
+      unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+      if (!valid) field = 0xFFFFu;
+      MAS_UNROLL for (int sh = LPA; sh < 64; sh <<= 1) field &= static_cast<unsigned>(__shfl_xor(static_cast<int>(field), sh));
+      post(t * LadderSync::kChunks + chunk, field);
+      const unsigned agreed = wait(t * LadderSync::kChunks + chunk);
+      if (agreed != 0u) { win = base + __builtin_ctz(agreed); return; }
+      if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; return; }
+    }
+  };
+
+  // two register sets (Front, Tile) alternate from step to step; written out by name -- indexing them with the parity of t would
+  // put them in scratch memory
+  Tile tileA, tileB;
+  Front frA, frB;
+  // one step: `cur` = front(t) (settled, posted), `tile_next` holds tile t-1, `tile_refill` held tile t and is refilled with t-2
+  auto iterate = [&](int t, int par, Front& cur, Front& nxt, Tile& tile_next, Tile& tile_refill) {
+    if (t > 1) fetch(tile_refill, t - 2);                       // tile t is no longer needed (front(t) is settled): a whole step ahead of its use
+    const bool speculate = (cur.field & 1u) != 0u;             // rung 0 works for every agent of this wavefront
+    if (speculate) {
+      back(t, par, cur, cur.Lcand, 0);
+      if (t > 0) front(tile_next, par ^ 1, nxt);
+    }
+    const unsigned agreed = wait(t * LadderSync::kChunks);
+    int win;
+    if (agreed != 0u) win = __builtin_ctz(agreed); else settle_beyond(t, cur, win);
+    if (!(speculate && win == 0)) {                             // not speculated, or speculated wrongly: the step with the agreed rung
+      back(t, par, cur, cur.Lcand, win & (LL - 1));
+      if (t > 0) front(tile_next, par ^ 1, nxt);
+    }
+    if (lane == 0 && a == 0) regs += win;                       // the stacked solve counts its rungs once (agent 0)
+    if (t > 0) post((t - 1) * LadderSync::kChunks, nxt.field);
+  };
+  int t = d.T - 1;
+  fetch(tileA, t);
+  if (t > 0) fetch(tileB, t - 1);
+  front(tileA, 0, frA);
+  post(t * LadderSync::kChunks, frA.field);
+  for (; t >= 1; t -= 2) { iterate(t, 0, frA, frB, tileB, tileA); iterate(t - 1, 1, frB, frA, tileA, tileB); }
+  if (t == 0) iterate(0, 0, frA, frB, tileB, tileA);
   if (valid && lane == 0) reg_events[a] += regs;
 }
 

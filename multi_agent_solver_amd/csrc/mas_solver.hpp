@@ -591,7 +591,13 @@ class SolverImpl final : public SolverBase {
   using BackwardKernelFn = void (*)(Dims, ModelParams, const double*, const double*, double*, double*, long long*, const int*, int, int, LadderSync);
   template <int W>
   static BackwardKernelFn central_kernel() {
-    if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) { if (!backward_tile_forced()) return mas_backward_row_kernel<M, true, W>; }
+    if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) {
+      if (!backward_tile_forced()) {
+        const char* e = std::getenv("MAS_HIP_CENTRAL_PIPELINE");       // A/B: 0 = the plain registers + DPP kernel with the shared ladder
+        if (e && e[0] == '0') return mas_backward_row_kernel<M, true, W>;
+        return mas_backward_row_pipelined_kernel<M, W>;
+      }
+    }
     return mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, W>;
   }
   static bool backward_tile_forced() { const char* e = std::getenv("MAS_HIP_BACKWARD_TILE"); return e && e[0] == '1'; }   // A/B: the LDS-tile kernel also for NX == 4
