@@ -481,6 +481,7 @@ struct BackwardTileLayout {
 struct LadderSync {
   unsigned long long* words = nullptr;   // [T * kChunks][4] (one used), preset to zero
   int* error = nullptr;
+  int xcd_stride = 1;                    // pipelined kernel: 8 = only every eighth workgroup works (the others exit at once), which puts all working workgroups on ONE XCD (workgroups are dealt round-robin over the 8 XCDs; tools/ubench/xcd_barrier.hip checks that through HW_REG_XCC_ID): their arrive-and-wait then stays inside one L2 (0.72 against 0.87 us bare).  Placement only -- the agreement is correct wherever the workgroups run
   int combine = 1;                       // workgroups of several wavefronts: combine their masks through LDS and arrive once per workgroup (measured on C2, us per pass: 245 against 546 when each of the 64 wavefronts arrives itself; single-wavefront workgroups: 253)
   static constexpr int kChunks = 32, kArrivalShift = 32;
 };
@@ -1220,7 +1221,9 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   const int wave = static_cast<int>(threadIdx.x) >> 6;
   const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane;
   const int i = lane & 3, j = lane >> 2, iu = (i < NU) ? i : NU - 1, ju = (j < NU) ? j : NU - 1;
-  const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
+  if (static_cast<int>(blockIdx.x) % sync.xcd_stride != 0) return;    // (one-XCD placement: see LadderSync::xcd_stride)
+  const int group = static_cast<int>(blockIdx.x) / sync.xcd_stride, n_groups = static_cast<int>(gridDim.x) / sync.xcd_stride;
+  const int a0 = lo + (group * WPB + wave) * APW, a = a0 + slot;
   const bool valid = (a < n) && active[a] != 0;
   if (active[lo] == 0) return;                               // the stacked solve has ended (all flags fall together): uniform over the whole launch
   double* T = lds + (wave * APW + slot) * STRIDE;
@@ -1372,7 +1375,7 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   };
 
   // the agreement, split in two: arrive (every wavefront / one per workgroup) and wait
-  const bool one_group = gridDim.x == 1;
+  const bool one_group = n_groups == 1;
   auto post = [&](int word, unsigned field) {
     if constexpr (WPB > 1) {
       if (tid == 0) blk_field[agreement_parity][wave] = field;
@@ -1390,12 +1393,12 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   auto wait = [&](int word) -> unsigned {
     unsigned agreed;
     if constexpr (WPB > 1) {
-      if (wave == 0 && !one_group) { const unsigned g = ladder_wait(sync, word, static_cast<int>(gridDim.x)); if (tid == 0) blk_agreed[agreement_parity] = g; }
+      if (wave == 0 && !one_group) { const unsigned g = ladder_wait(sync, word, n_groups); if (tid == 0) blk_agreed[agreement_parity] = g; }
       __syncthreads();
       agreed = blk_agreed[agreement_parity];
       agreement_parity ^= 1u;
     } else {
-      agreed = ladder_wait(sync, word, static_cast<int>(gridDim.x));
+      agreed = ladder_wait(sync, word, n_groups);
     }
     return agreed;
   };

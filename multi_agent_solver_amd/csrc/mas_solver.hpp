@@ -541,7 +541,11 @@ class SolverImpl final : public SolverBase {
       const int wpb = central_waves_per_block();
       auto launch = [&](auto kernel, int w) {
         const int agents_per_block = apw * w;
-        be.launch_kernel(kernel, dim3((d.N + agents_per_block - 1) / agents_per_block), dim3(64 * w), d, P, X, D, kff, Kfb,
+        const int groups = (d.N + agents_per_block - 1) / agents_per_block;
+        // up to 32 working workgroups (one per CU of an XCD) are placed on ONE XCD by launching eight times as many and letting
+        // every eighth work (LadderSync::xcd_stride); only the pipelined kernel knows the stride
+        sy.xcd_stride = (central_pipelined() && groups > 1 && groups <= 32 && central_one_xcd()) ? 8 : 1;
+        be.launch_kernel(kernel, dim3(groups * sy.xcd_stride), dim3(64 * w), d, P, X, D, kff, Kfb,
                          reg_events, active, 0, static_cast<int>(d.N), sy);
       };
       if (wpb == 16) launch(central_kernel<16>(), 16);
@@ -593,13 +597,19 @@ class SolverImpl final : public SolverBase {
   static BackwardKernelFn central_kernel() {
     if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) {
       if (!backward_tile_forced()) {
-        const char* e = std::getenv("MAS_HIP_CENTRAL_PIPELINE");       // A/B: 0 = the plain registers + DPP kernel with the shared ladder
-        if (e && e[0] == '0') return mas_backward_row_kernel<M, true, W>;
+        if (!central_pipelined()) return mas_backward_row_kernel<M, true, W>;
         return mas_backward_row_pipelined_kernel<M, W>;
       }
     }
     return mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, W>;
   }
+  static bool central_pipelined() {                                    // A/B: MAS_HIP_CENTRAL_PIPELINE=0 = the plain registers + DPP kernel with the shared ladder
+    if constexpr (!(NX == 4 && kBackwardLanesPerAgent == 16)) return false;
+    if (backward_tile_forced()) return false;
+    const char* e = std::getenv("MAS_HIP_CENTRAL_PIPELINE");
+    return !(e && e[0] == '0');
+  }
+  static bool central_one_xcd() { const char* e = std::getenv("MAS_HIP_CENTRAL_ONE_XCD"); return !(e && e[0] == '0'); }
   static bool backward_tile_forced() { const char* e = std::getenv("MAS_HIP_BACKWARD_TILE"); return e && e[0] == '1'; }   // A/B: the LDS-tile kernel also for NX == 4
   // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
   // them resident at once.  Checked against the occupancy the runtime reports for this kernel on this device (a
