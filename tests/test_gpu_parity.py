@@ -448,3 +448,28 @@ def test_kernel_forms_agree(gpu_lib, oracle, monkeypatch, model, T, dt, strategy
     assert new["stats"]["reg_events"] == old["stats"]["reg_events"]
     o = oracle.solve_batch(mid, x0, None, T, dt, strategy=strategy, max_outer=outer)
     _same(new, o, total_exact=(strategy != "centralized"))
+
+
+@pytest.mark.parametrize("model,N,T", [("MODEL_SINGLE_TRACK", 10, 30), ("MODEL_SINGLE_TRACK", 70, 40), ("MODEL_SINGLE_TRACK", 600, 25),
+                                       ("MODEL_LQR_IDENTITY", 40, 20), ("MODEL_SINGLE_TRACK_LANE", 90, 30)])
+def test_centralized_speculative_pass_agrees(gpu_lib, oracle, monkeypatch, model, N, T):
+    """The centralised backward pass hides the rung agreement behind a speculative step (mas_backward_row_pipelined_kernel): one
+    workgroup (N = 10), several on one XCD (70, 40, 90), more than an XCD holds (600); NU = 2 and NU = 4; perturbed agents, so that
+    the agreed rung often differs from the one a wavefront assumed and steps are redone.  Same results as the plain kernel with
+    the shared ladder, as the LDS-tile kernel, and as the oracle."""
+    mid = getattr(oracle, model)
+    rng = np.random.default_rng(11)
+    base = oracle.lqr_x0(N) if model == "MODEL_LQR_IDENTITY" else oracle.single_track_x0(N)
+    x0 = base + 0.05 * rng.standard_normal(base.shape)
+    dt = 0.1 if model != "MODEL_SINGLE_TRACK" else 0.5
+    new = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
+    monkeypatch.setenv("MAS_HIP_CENTRAL_PIPELINE", "0")
+    plain = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
+    monkeypatch.setenv("MAS_HIP_BACKWARD_TILE", "1")
+    tile = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
+    for other in (plain, tile):
+        for key in ("cost", "X", "U", "iters"):
+            assert np.array_equal(new[key], other[key]), key
+        assert new["stats"]["reg_events"] == other["stats"]["reg_events"] and new["total_cost"] == other["total_cost"]
+    o = oracle.solve_batch(mid, x0, None, T, dt, strategy="centralized", max_outer=1)
+    _same(new, o, total_exact=False)
