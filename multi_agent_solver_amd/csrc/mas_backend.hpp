@@ -51,6 +51,7 @@ struct Backend {
   void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void d2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void zero(void* d, size_t n) { std::memset(d, 0, n); }
+  void fill32(int* d, int v, size_t count) { for (size_t i = 0; i < count; ++i) d[i] = v; }
   void sync() {}
   void resolve_profile() {}
   // events (no-ops here: the emulation runs everything in program order)
@@ -189,6 +190,7 @@ struct Backend {
   void d2h(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream)); MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
   void d2d(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, cur)); }
   void zero(void* d, size_t n) { MAS_HIP_CHECK(hipMemsetAsync(d, 0, n, cur)); }
+  void fill32(int* d, int v, size_t count) { MAS_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d), v, count, cur)); }
   void sync() { MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
 
   hipEvent_t get_event() {

@@ -314,7 +314,9 @@ class SolverImpl final : public SolverBase {
       launch_sweep(sweep_bytes() * nact);
       launch_central_backward(backward_bytes() * nact);
       launch_forward(make_forward(), forward_bytes() * nact * kNumAlphas, nullptr, nullptr, d.N);     // every agent active: slot == agent, CommitBody serves both forms
-      be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr}, d.N);
+      // one wavefront per alpha trial for the ten serial sums (at least ten wavefronts, and a thread per agent for the bookkeeping)
+      be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr}, d.N,
+                      0.0, 0, std::max(64 * kNumAlphas, static_cast<int>((d.N + 63) / 64 * 64)));
       static_assert(sizeof(CentralState) % sizeof(long long) == 0, "published word by word");
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U,
                                Publish{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long))}}, d.N, d.T + 1);
@@ -822,7 +824,7 @@ class SolverImpl final : public SolverBase {
     double c = 0.0; for (double v : h) c += v; return c;
   }
   void fill(double* dev, double v) { std::vector<double> h(d.Np, v); be.h2d(dev, h.data(), sizeof(double) * d.Np); }
-  void fill_int(int* dev, int v) { std::vector<int> h(d.Np, v); be.h2d(dev, h.data(), sizeof(int) * d.Np); }
+  void fill_int(int* dev, int v) { be.fill32(dev, v, d.Np); }       // on the stream, no host round trip
   // device pointers: the copy runs on the handle's stream and is complete on return, so the caller's buffer is no longer
   // referenced afterwards; the caller must have made its contents ready before the call (mas_hip.h, stream-ordering contract)
   void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); be.sync(); } else be.h2d(stage, src, sizeof(double) * n); }
