@@ -28,6 +28,8 @@ def classify(name):
     # <Model, 16, true, WPB> (LDS-tile form) / <Model, true, WPB> (registers + DPP form): the shared ladder of the centralised strategy
     if ("mas_backward_tile_kernel" in head or "mas_backward_row_kernel" in head) and ", true" in head:
         return "central_backward"
+    if "mas_backward_row_pipelined_kernel" in head:      # the shared ladder behind a speculative step
+        return "central_backward"
     for key, pats in KERNELS:
         if any(p in name for p in pats):
             return key
