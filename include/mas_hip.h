@@ -31,8 +31,8 @@
  *
  * Device exclusivity of the centralised strategy
  *    mas_hip_run_centralized agrees on one regularisation rung per time step across all its workgroups with a spin barrier
- *    in global memory, which needs all of them (N/4 single-wavefront workgroups, N <= 1024) resident on the device at the
- *    same time.  The library checks that they fit this device (occupancy query) and otherwise uses a slower single-workgroup
+ *    in global memory, which needs all of them (N/16 four-wavefront workgroups, N <= 1024; up to 32 of them are placed on one
+ *    XCD) resident on the device at the same time.  The library checks that they fit this device (occupancy query) and otherwise uses a slower single-workgroup
  *    kernel, but it cannot see OTHER work: do not run kernels from other streams or processes on the device while a
  *    centralised solve is in flight.  If the barrier starves, the call fails with MAS_HIP_ERR_RUNTIME ("gave up waiting for
  *    the rung agreement") instead of hanging.
