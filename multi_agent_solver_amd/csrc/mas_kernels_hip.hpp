@@ -481,6 +481,11 @@ struct BackwardTileLayout {
 struct LadderSync {
   unsigned long long* words = nullptr;   // [T * kChunks][4] (one used), preset to zero
   int* error = nullptr;
+  // (not part of the agreement; carried here because every backward kernel shares one signature)  Per-agent LDS-tile kernel: the
+  // round's compacted list of live agents -- wavefront slot s works on agent live_list[s], so the launch shrinks with the live
+  // agents.  With two wavefronts per SIMD (8192 six-state agents = 2048 wavefronts) that halves the time of the tail rounds,
+  // where almost every group of four consecutive agents still holds a live one.  null: slot s = agent lo + s, `active` decides.
+  const int* live_list = nullptr; const int* live_count = nullptr;
   int xcd_stride = 1;                    // pipelined kernel: 8 = only every eighth workgroup works (the others exit at once), which puts all working workgroups on ONE XCD (workgroups are dealt round-robin over the 8 XCDs; tools/ubench/xcd_barrier.hip checks that through HW_REG_XCC_ID): their arrive-and-wait then stays inside one L2 (0.72 against 0.87 us bare).  Placement only -- the agreement is correct wherever the workgroups run
   int combine = 1;                       // workgroups of several wavefronts: combine their masks through LDS and arrive once per workgroup (measured on C2, us per pass: 245 against 546 when each of the 64 wavefronts arrives itself; single-wavefront workgroups: 253)
   static constexpr int kChunks = 32, kArrivalShift = 32;
@@ -549,8 +554,19 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
 
   const int wave = static_cast<int>(threadIdx.x) >> 6;    // 0 when WPB == 1
   const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
-  const int a0 = lo + (static_cast<int>(blockIdx.x) * WPB + wave) * APW, a = a0 + slot;
-  const bool valid = (a < n) && active[a] != 0;
+  const int slot0 = (static_cast<int>(blockIdx.x) * WPB + wave) * APW;
+  int a = lo + slot0 + slot;
+  bool valid, counted;
+  if (!SharedLadder && sync.live_list != nullptr) {
+    const int n_live = *sync.live_count;                    // uniform
+    if (slot0 >= n_live) return;
+    counted = slot0 + slot < n_live;
+    a = sync.live_list[counted ? slot0 + slot : slot0];     // a surplus slot of the last wavefront repeats its first agent: same values to the same addresses
+    valid = true;
+  } else {
+    valid = (a < n) && active[a] != 0;
+    counted = valid;
+  }
   if (!SharedLadder && __ballot(valid) == 0ull) return;   // uniform for the (single-wave) block; a shared ladder needs every wavefront
   if (SharedLadder && active[lo] == 0) return;             // the stacked solve has ended (all flags fall together): uniform over the whole launch
   const int tile = wave * APW + slot;
@@ -612,12 +628,12 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
     const bool mine = lane < cw;
     const int e = mine ? lane : cw - 1;
-    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
+    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(a / 64) * 64 * ND + static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
     publish_at[c] = tile * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
   }
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
-  // (the 64-agent block of a wavefront is uniform: said explicitly, so that the base pointer lives in scalar registers)
-  const double* tiles_t = D + (static_cast<size_t>(d.T - 1) * (d.Np / 64) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(a0 / 64))) * 64 * ND;
+  // (uniform base = the tiles of a time step; the agent's 64-block is part of the lane offset, so that listed agents may come from anywhere)
+  const double* tiles_t = D + static_cast<size_t>(d.T - 1) * step_doubles;
   auto fetch = [&]() { MAS_UNROLL for (int c = 0; c < NCH; ++c) pre[c] = ld_off(tiles_t, fetch_off[c]); };
   long long regs = 0;
   // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
@@ -845,7 +861,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   };
   step(d.T - 1);
   for (int t = d.T - 2; t >= 0; --t) step(t);
-  if (valid && lane == 0) reg_events[a] += regs;
+  if (counted && lane == 0) reg_events[a] += regs;
 }
 
 // ------------------------------------------------ backward, 16 lanes/agent, NX == 4: registers + DPP --

@@ -567,7 +567,10 @@ class SolverImpl final : public SolverBase {
   }
   // backward Riccati pass: 16 lanes per agent over LDS tiles on the GPU, scalar body in the emulation
   void launch_backward(double bytes) { launch_backward(bytes, 0, d.N); }
-  void launch_backward(double bytes, int lo, int hi) {
+  // live_list / live_count / slots: the round's compacted list of live agents, its device-side length and a host-side upper bound
+  // of it (LDS-tile kernel only: LadderSync::live_list); null = agents lo .. hi-1 by their flags
+  void launch_backward(double bytes, int lo, int hi, const int* live_list = nullptr, const int* live_count = nullptr, long long slots = 0) {
+    (void)live_list; (void)live_count; (void)slots;
 #if defined(MAS_HOST_EMULATION)
     be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active, al_view(al_enabled)}, lo, hi, bytes);
 #else
@@ -586,8 +589,14 @@ class SolverImpl final : public SolverBase {
         return;
       }
     }
-    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false, wpb>, grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
-                     reg_events, active, lo, hi, LadderSync{});
+    LadderSync extras{};
+    dim3 tile_grid = grid;
+    if (live_list != nullptr && backward_list_enabled()) {
+      extras.live_list = live_list; extras.live_count = live_count;
+      tile_grid = dim3(static_cast<unsigned>((slots + wpb * apw - 1) / (wpb * apw)));
+    }
+    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false, wpb>, tile_grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
+                     reg_events, active, lo, hi, extras);
     be.end();
 #endif
   }
@@ -611,6 +620,7 @@ class SolverImpl final : public SolverBase {
     const char* e = std::getenv("MAS_HIP_CENTRAL_PIPELINE");
     return !(e && e[0] == '0');
   }
+  static bool backward_list_enabled() { const char* e = std::getenv("MAS_HIP_BACKWARD_LIST"); return !(e && e[0] == '0'); }   // A/B: 0 = the LDS-tile kernel walks all agents by their flags
   static bool central_one_xcd() { const char* e = std::getenv("MAS_HIP_CENTRAL_ONE_XCD"); return !(e && e[0] == '0'); }
   static bool backward_tile_forced() { const char* e = std::getenv("MAS_HIP_BACKWARD_TILE"); return e && e[0] == '1'; }   // A/B: the LDS-tile kernel also for NX == 4
   // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
@@ -730,7 +740,7 @@ class SolverImpl final : public SolverBase {
       // two lists: round r walks list r & 1 (sweep, quad line search, commit) while its select compacts the next round's
       const int* list_now = live_lists[r & 1]; int* list_next = live_lists[(r + 1) & 1];
       launch_sweep(sweep_bytes(), 0, d.N, live, live ? static_cast<int>(live_upper) : d.N, list_now);
-      launch_backward(backward_bytes(), 0, d.N);
+      launch_backward(backward_bytes(), 0, d.N, live ? list_now : nullptr, live, live_upper);
       const bool by_slot = live ? launch_forward(fwd, forward_bytes() * kNumAlphas, list_now, live, live_upper)
                                 : launch_forward(fwd, forward_bytes() * kNumAlphas, nullptr, nullptr, std::numeric_limits<long long>::max());
       long long* ctr = counters + 2 * (r % kCounterRing);
