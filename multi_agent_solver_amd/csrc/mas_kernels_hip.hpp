@@ -919,6 +919,11 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
   // difference Hessians a quarter of the steps need rungs 5-12 and a wavefront of four agents rarely passes as a whole: measured
   // on C3 the attempt costs as much as it saves (91.3 -> 93 us), so those models go straight to the 16-rung form.
   constexpr bool kRung0First = M::kAnalyticLuu && !SharedLadder;
+#if defined(MAS_BWD_FACTOR_LDS)
+  constexpr bool kFactorByPermute = false;
+#else
+  constexpr bool kFactorByPermute = NU <= 2;
+#endif
   __shared__ double lds[WPB * APW * STRIDE];
   __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];
   __shared__ unsigned blk_agreed[2];
@@ -1141,10 +1146,23 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
             }
           }
         }
-        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lfac[e]; }
         if (lane == 0 && (!SharedLadder || a == 0)) regs += win;
+        if constexpr (kFactorByPermute) {
+          // the factor of the winning rung straight from its lane (ds_bpermute: the LDS crossbar without a write -> wait -> read):
+          // three entries of a 2 x 2 factor (the strictly upper one is never read), six dword permutes
+          const int src = ((tid & ~(LPA - 1)) + (win & (LL - 1))) * 4;
+          MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+            if (e % NU >= e / NU) {                                  // column-major: row >= column
+              const int lo32 = __builtin_amdgcn_ds_bpermute(src, __double2loint(Lfac[e])), hi32 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(Lfac[e]));
+              Lfac[e] = __hiloint2double(hi32, lo32);
+            }
+          }
+          wave_sync();                                               // the pass-2 outputs before the reads below
+        } else {
+        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lfac[e]; }
         wave_sync();                                                 // also orders the pass-2 outputs before the reads below
         MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+        }
         } else {
           wave_sync();                                               // the pass-2 outputs before the reads below
         }
@@ -1353,9 +1371,21 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   auto back = [&](int t, int par, const Front& f, const double* Lsrc, int src) {
     const int R2 = oR2 + par * kR2;
     double Lfac[NU * NU], ninv[NU * NU], kf[NU];
-    if (lane == src) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lsrc[e]; }
-    wave_sync();                                                 // also orders the pass-2 outputs before the reads below
-    MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+    if constexpr (NU <= 2) {                                     // the factor straight from its lane (see mas_backward_row_kernel)
+      const int srcaddr = ((tid & ~(LPA - 1)) + src) * 4;
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+        Lfac[e] = Lsrc[e];
+        if (e % NU >= e / NU) {
+          const int lo32 = __builtin_amdgcn_ds_bpermute(srcaddr, __double2loint(Lsrc[e])), hi32 = __builtin_amdgcn_ds_bpermute(srcaddr, __double2hiint(Lsrc[e]));
+          Lfac[e] = __hiloint2double(hi32, lo32);
+        }
+      }
+      wave_sync();                                               // the pass-2 outputs before the reads below
+    } else {
+      if (lane == src) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lsrc[e]; }
+      wave_sync();                                               // also orders the pass-2 outputs before the reads below
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+    }
     double* kff_t = kff + static_cast<size_t>(t) * NU * d.Np;
     double* Kfb_t = Kfb + static_cast<size_t>(t) * NU * NX * d.Np;
     llt_solve_identity<NU>(Lfac, ninv);
