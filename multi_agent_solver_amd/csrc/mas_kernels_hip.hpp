@@ -1,21 +1,24 @@
-// mas_kernels_hip.hpp -- the two hand-shaped gfx950 kernels of the iteration (HIP build only).
+// mas_kernels_hip.hpp -- the hand-shaped gfx950 kernels of the iteration (HIP build only).
 //
-//  * mas_sweep_kernel      linearisation sweep, one lane per (agent, t).  Each lane produces one
-//                          derivative tile (ND doubles) in registers; the wavefront stages the tiles
-//                          through LDS in 16-element chunks so that every global store instruction
-//                          writes contiguous 128-byte runs of the [t][agent][ND] tile array.  Inside a solve
-//                          the wavefront slots walk the compacted list of still-active agents.
-//  * mas_backward_tile_kernel  backward Riccati recursion with SIXTEEN lanes per agent (a wavefront =
-//                          4 agents): the small dense products of ilqr.hpp:115-119,183-192 are spread
-//                          element-wise over the 16 lanes, operands live in an LDS tile per agent.
-//                          The recursion is a dependency chain in t; per lane it is ~5x shorter than
-//                          the one-lane-per-agent form (BackwardBody), which remains the host-emulated
-//                          statement of the same arithmetic: every output element is the same sequence
-//                          of multiplies and adds (sums in k order from 0.0), so results are bit-equal.
-//                          Its time-step loop is written against the gfx950 ISA it compiles to: a lone
-//                          wavefront per SIMD pays 5-7 clock ticks per instruction, so the loop avoids
-//                          selects (loop-invariant -0.0 addends), predication (clamped prefetch lanes)
-//                          and vector address arithmetic (scalar base + 32-bit lane offsets).
+//  * mas_sweep_kernel            linearisation sweep, one lane per (agent, t).  Each lane produces one derivative tile (ND doubles)
+//                                in registers; the wavefront stages the tiles through LDS in 16-element chunks so that every global
+//                                store instruction writes contiguous 128-byte runs of the tile array.  Inside a solve the wavefront
+//                                slots walk the compacted list of still-active agents.
+//  * mas_forward_quad_kernel,    line search / initial rollout / trust-region re-roll with FOUR lanes per rollout, one per RK4 stage
+//    mas_rollout_quad_kernel,    (QuadRk4): for launches whose rollouts do not fill the chip, where the launch time is one wavefront's
+//    mas_trust_reroll_quad_kernel chain.  The one-lane forms are ForwardBody / RolloutCostBody / TrustRerollBody (mas_bodies.hpp).
+//  * mas_backward_row_kernel     backward Riccati recursion for NX == 4: the 16 lanes of an agent are one DPP row holding the 4 x 4
+//                                value Hessian; V and the tiles never touch LDS (quad_perm / row_newbcast / direct loads), one LDS
+//                                round trip per step.
+//  * mas_backward_row_pipelined_kernel  the same with the shared ladder of the centralised strategy, the cross-workgroup rung
+//                                agreement hidden behind a speculative step.
+//  * mas_backward_tile_kernel    backward recursion for any NX with SIXTEEN lanes per agent over an LDS tile per agent: the small
+//                                dense products of ilqr.hpp:115-119,183-192 are spread element-wise over the 16 lanes.
+// All backward kernels compute, element for element, the arithmetic of BackwardBody (the one-lane form the host emulation
+// replays): every output element is the same sequence of multiplies and adds, sums in k order (sum_terms: from the first term).
+// Their time-step loops are written against the gfx950 ISA they compile to: a lone wavefront per SIMD pays 5.5-7 clock ticks per
+// instruction whatever its instruction-level parallelism, so the loops avoid selects (loop-invariant -0.0 addends), predication
+// (clamped prefetch lanes), vector address arithmetic (scalar base + 32-bit lane offsets) and LDS round trips.
 //
 // No MFMA: v_mfma_f64_4x4x4 fuses the multiply-adds of a dot product, the reference (SSE2, no FMA;
 // CMakeLists.txt sets no -march) rounds after every multiply -- and the algorithm amplifies last-bit
