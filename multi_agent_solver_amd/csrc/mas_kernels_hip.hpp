@@ -425,6 +425,15 @@ __global__ void __launch_bounds__(256) mas_trust_reroll_quad_kernel(const TrustR
   if (act && s == 0) f.ts.finish(a, c, f.ts.radii[a]);
 }
 
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
+}
+// q_uu entries from the pass-2 results of the LDS-tile kernel: entry e is item W0 + e, formed in round (W0 + e) / 16 by lane (W0 + e) % 16
+template <int W0, int R2, int... E>
+__device__ __forceinline__ void tile_gather_quu(const double (&res)[R2], double* quu, std::integer_sequence<int, E...>) {
+  ((quu[E] = row_bcast<(W0 + E) % 16>(res[(W0 + E) / 16])), ...);
+}
 // sum of N terms in index order, starting FROM THE FIRST TERM -- as Eigen's redux does for the reference's small products.  The
 // CPU oracle and the one-lane bodies start from +0.0 (s = 0.0; s += term_k); the two agree in every bit except that an
 // all-zero sum can come out as -0.0 here and +0.0 there.  No operation of the path tells the two zeros apart (it never
@@ -698,8 +707,13 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
         res[r] = T[b2[r]] + s;
       }
       MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
+      if constexpr (!kLocalQuu && LPA == 16) {
+        // q_uu straight from the lanes that formed it (item NX^2 + NU NX + e sits in round (..) / 16 on lane (..) % 16, and an agent's 16
+        // lanes are one DPP row): the LLT / ladder chain starts without waiting for the LDS round trip of the other pass-2 results
+        tile_gather_quu<NX * NX + NU * NX, R2>(res, quu, std::make_integer_sequence<int, NU * NU>{});
+      }
     }
-    if constexpr (!kLocalQuu) {
+    if constexpr (!kLocalQuu && LPA != 16) {
       wave_sync();
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
     }
@@ -795,10 +809,22 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
           }
         }
         }
-        if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oL + i] = Lfac[i]; }
         if (lane == 0 && (!SharedLadder || a == 0)) regs += win;         // the stacked solve counts its rungs once (agent 0)
-        wave_sync();                                                 // also orders the pass-2 outputs before the reads below
-        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oL + i];
+        if constexpr (NU <= 2 && LPA == 16) {
+          // the factor of the winning rung straight from its lane (ds_bpermute), see mas_backward_row_kernel
+          const int src = ((tid & ~(LPA - 1)) + (win & (LL - 1))) * 4;
+          MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+            if (e % NU >= e / NU) {
+              const int lo32 = __builtin_amdgcn_ds_bpermute(src, __double2loint(Lfac[e])), hi32 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(Lfac[e]));
+              Lfac[e] = __hiloint2double(hi32, lo32);
+            }
+          }
+          wave_sync();                                               // the pass-2 outputs before the reads below
+        } else {
+          if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oL + i] = Lfac[i]; }
+          wave_sync();                                               // also orders the pass-2 outputs before the reads below
+          MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oL + i];
+        }
       }
       MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
       llt_solve_identity<NU>(Lfac, ninv);                           // Quu_reg^-1, :183
@@ -884,10 +910,6 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
 //   pass 2   q_xx(i,j), q_ux(i,j) [i < NU], q_uu(i,j) [i, j < NU]
 //   pass 3   as in the tile kernel
 // Every output element is the same sequence of multiplies and adds as in the tile kernel and in BackwardBody.
-template <int SRC>
-__device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
-  return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
-}
 __device__ __forceinline__ double2 ld2_off(const double* base, unsigned byte_off) { return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + byte_off); }
 // out[e] = the value lane (I0 + e % NU, e / NU) of the row holds, e < NU * NU (q_uu); out[m] = lane m's (q_u); out[m] = lane m of the quad's (q_ux column)
 template <int NU, int I0, int... E>
