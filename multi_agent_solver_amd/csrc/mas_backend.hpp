@@ -184,7 +184,9 @@ struct Backend {
     return p;
   }
   void free(void* p) { if (p) (void)hipFree(p); }
-  void* alloc_pinned(size_t bytes) { void* p = nullptr; MAS_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault)); return p; }
+  // pinned, device-mapped and COHERENT (fine-grained): the commit kernel publishes a round's counters into it (Publish, mas_bodies.hpp)
+  // and the host reads them after the round's event -- stated explicitly rather than left to HIP_HOST_COHERENT's default
+  void* alloc_pinned(size_t bytes) { void* p = nullptr; MAS_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocMapped | hipHostMallocCoherent)); return p; }
   void free_pinned(void* p) { if (p) (void)hipHostFree(p); }
   void h2d(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream)); MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
   void d2h(void* d, const void* s, size_t n) { MAS_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream)); MAS_HIP_CHECK(hipStreamSynchronize(stream)); }
