@@ -376,7 +376,11 @@ struct SelectBody {
 // kernel per round (hipMemcpyAsync: ~4 us of kernel + ~6 us of gap in the trace) would sit on every round's critical path.
 struct Publish {
   const long long* src = nullptr; long long* host = nullptr; int words = 0;
-  MAS_HD void operator()() const { for (int i = 0; i < words; ++i) host[i] = src[i]; }
+  const int* flag = nullptr;        // optional: one more word, host[words] = *flag (the centralised pass's "gave up waiting" flag)
+  MAS_HD void operator()() const {
+    for (int i = 0; i < words; ++i) host[i] = src[i];
+    if (flag) host[words] = static_cast<long long>(*flag);
+  }
 };
 
 template <class M>

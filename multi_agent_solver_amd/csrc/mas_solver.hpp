@@ -137,7 +137,7 @@ class SolverImpl final : public SolverBase {
     const size_t stage_elems = static_cast<size_t>(d.N) * std::max<size_t>(static_cast<size_t>(T + 1) * NX, static_cast<size_t>(T) * std::max(L::ND, NU * NX));
     stage = dalloc(stage_elems);
     host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 32));
-    host_central = static_cast<CentralState*>(be.alloc_pinned(2 * sizeof(CentralState)));   // two read-back slots (the centralised loop runs one iteration ahead)
+    host_central = static_cast<HostCentral*>(be.alloc_pinned(2 * sizeof(HostCentral)));   // two read-back slots (the centralised loop runs one iteration ahead)
     be.sync();
   }
   ~SolverImpl() override {
@@ -158,6 +158,7 @@ class SolverImpl final : public SolverBase {
     have_x0 = true; initialized = false; rollout_consistent = false;
   }
   void set_controls(const double* src, bool device_ptr) override {
+    controls_zero = (src == nullptr);
     if (!src) { be.zero(U, sizeof(double) * d.T * NU * d.Np); }
     else {
       upload(src, static_cast<size_t>(d.N) * d.T * NU, device_ptr);
@@ -201,10 +202,12 @@ class SolverImpl final : public SolverBase {
   }
   void save_initial() override {
     be.d2d(x0_saved, x0, sizeof(double) * NX * d.Np); be.d2d(U_saved, U, sizeof(double) * d.T * NU * d.Np); saved = true;
+    saved_controls_zero = controls_zero;
   }
   void restore_initial() override {
     require(saved, "no saved initial state");
     be.d2d(x0, x0_saved, sizeof(double) * NX * d.Np); be.d2d(U, U_saved, sizeof(double) * d.T * NU * d.Np);
+    controls_zero = saved_controls_zero;
     be.zero(iters_total, sizeof(int) * d.Np);   // per-agent iteration counts restart with the problem; reg_events keeps counting since reset_stats (no read-back here)
     have_x0 = true;
     initialize_problem();
@@ -287,8 +290,12 @@ class SolverImpl final : public SolverBase {
     al_enabled = false;                                  // build_global_ocp stacks no constraint functions
     require(have_x0, "initial states not set");
     require(d.N <= kCentralMaxAgents, "centralized strategy supports at most 1024 agents per device");
-    be.zero(U, sizeof(double) * d.T * NU * d.Np);       // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109)
-    initialize_problem();
+    // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109); if the device already holds zero
+    // controls and their rollout (set_controls(null) / a restore of such a state, then initialize_problem), that is this very state
+    if (!(controls_zero && initialized && rollout_consistent)) {
+      be.zero(U, sizeof(double) * d.T * NU * d.Np);
+      initialize_problem();
+    }
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
     be.launch_group("central_init", CentralInitBody{d, cost, central}, d.N);
     stats.solves += 1;
@@ -307,6 +314,7 @@ class SolverImpl final : public SolverBase {
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
     int enq = 0;
+    CentralState final_state{}; bool have_final = false, ladder_gave_up = false;
     auto enqueue = [&]() {
       Marks& mk = marks[enq & 1];
       mk.p0 = be.mark(); mk.s0 = stamp_launches.size();
@@ -319,7 +327,8 @@ class SolverImpl final : public SolverBase {
                       0.0, 0, std::max(64 * kNumAlphas, static_cast<int>((d.N + 63) / 64 * 64)));
       static_assert(sizeof(CentralState) % sizeof(long long) == 0, "published word by word");
       be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U,
-                               Publish{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long))}}, d.N, d.T + 1);
+                               Publish{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long)),
+                                       ladder_error_flag()}}, d.N, d.T + 1);
       be.record(round_ev[enq & 1]);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
       ++enq;
@@ -330,7 +339,9 @@ class SolverImpl final : public SolverBase {
       be.wait(round_ev[r & 1]);
       stats.agent_iterations += d.N;
       stats.batch_iterations++;
-      if (host_central[r & 1].done) {
+      final_state = host_central[r & 1].st; have_final = true;
+      if (host_central[r & 1].ladder_error != 0) ladder_gave_up = true;
+      if (final_state.done) {
         exit_reason = kExitConverged;
         if (enq > r + 1) {                               // the iteration enqueued ahead runs on no agent: nothing to account
           be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0);
@@ -341,11 +352,14 @@ class SolverImpl final : public SolverBase {
       if (enq == r + 1 && enq < max_iterations) { if (timed_out(t0)) { exit_reason = kExitTime; break; } enqueue(); }
     }
     if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);      // drain an iteration that ran ahead
-    check_ladder_sync();
-    be.d2h(host_central, central, sizeof(CentralState));
-    central_total = host_central->cur_total; last_total_valid = true;
+    if (ladder_gave_up) throw std::runtime_error("centralised backward pass: a wavefront gave up waiting for the rung agreement");   // (the flag is cleared with the words before every launch)
+    // the state after the last executed iteration was published with it (an iteration enqueued behind the last one leaves it as it is);
+    // only a solve without any iteration has to fetch what central_init wrote
+    if (!have_final) { be.d2h(&host_central[0].st, central, sizeof(CentralState)); final_state = host_central[0].st; }
+    central_total = final_state.cur_total; last_total_valid = true;
     if (exit_reason == kExitConverged) stats.converged_solves += 1;
     fill_int(exit_code, exit_reason);
+    controls_zero = false;
   }
 
   // centralized.hpp:18-38 in the reference's literal reading: ONE iLQR on the stacked OCP with finite differences of the
@@ -365,10 +379,12 @@ class SolverImpl final : public SolverBase {
     body.x0 = x0; body.X = X; body.U = U; body.cost = cost; body.iters_total = iters_total; body.exit_code = exit_code; body.reg_events = reg_events;
     body.st = central; body.ws = dense_ws; body.flags = dense_flags;
     be.launch_group("central_dense", body, d.N, 0.0, 0, /*threads=*/1024);
-    be.d2h(host_central, central, sizeof(CentralState));
-    central_total = host_central->cur_total; last_total_valid = true;
-    stats.solves += 1; stats.agent_iterations += static_cast<long long>(host_central->iterations) * d.N; stats.batch_iterations += host_central->iterations;
-    if (host_central->done) stats.converged_solves += 1;
+    be.d2h(&host_central[0].st, central, sizeof(CentralState));
+    const CentralState& hc = host_central[0].st;
+    central_total = hc.cur_total; last_total_valid = true;
+    stats.solves += 1; stats.agent_iterations += static_cast<long long>(hc.iterations) * d.N; stats.batch_iterations += hc.iterations;
+    if (hc.done) stats.converged_solves += 1;
+    controls_zero = false;
     initialized = false; rollout_consistent = false;     // cost[] now holds per-agent objectives of the stacked solution, merit[] is stale
   }
 
@@ -556,7 +572,6 @@ class SolverImpl final : public SolverBase {
       else if (wpb == 2) launch(central_kernel<2>(), 2);
       else launch(central_kernel<1>(), 1);
       be.end();
-      ladder_error_pending = true;
       return;
       }
     }
@@ -691,6 +706,7 @@ class SolverImpl final : public SolverBase {
   // trust_epilogue: every solve of the chain is followed by the agent's trust-region test (run_trust_region)
   void solve_all(int n_solves = 1, bool trust_epilogue = false) {
     ensure_initialized();
+    controls_zero = false;
     if (trust_epilogue && !trust_verdict) {
       trust_verdict = ialloc(d.Np); trust_ended = ialloc(d.Np); trust_roll_list = ialloc(d.Np); trust_roll_count = ialloc(16); trust_scale = dalloc(d.Np);
     }
@@ -840,14 +856,12 @@ class SolverImpl final : public SolverBase {
   void upload(const double* src, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(stage, src, sizeof(double) * n); be.sync(); } else be.h2d(stage, src, sizeof(double) * n); }
   void download(double* dst, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(dst, stage, sizeof(double) * n); be.sync(); } else be.d2h(dst, stage, sizeof(double) * n); }
   void* raw_alloc(size_t bytes) { void* p = be.alloc(bytes); allocations.push_back(p); return p; }   // freed by the destructor
-  void check_ladder_sync() {
+  // device address of the "gave up waiting" flag of the rung agreement (null while the single-workgroup fallback is in use)
+  const int* ladder_error_flag() const {
 #if !defined(MAS_HOST_EMULATION)
-    if (!ladder_error_pending || !ladder_sync) return;
-    ladder_error_pending = false;
-    int err = 0;
-    be.d2h(&err, ladder_sync + static_cast<size_t>(d.T) * LadderSync::kChunks * 4, sizeof(int));
-    if (err) throw std::runtime_error("centralised backward pass: a wavefront gave up waiting for the rung agreement");
+    if (ladder_sync) return reinterpret_cast<const int*>(ladder_sync + static_cast<size_t>(d.T) * LadderSync::kChunks * 4);
 #endif
+    return nullptr;
   }
   double* dalloc(size_t n) { void* p = be.alloc(sizeof(double) * n); allocations.push_back(p); return static_cast<double*>(p); }
   int* ialloc(size_t n) { void* p = be.alloc(sizeof(int) * n); allocations.push_back(p); return static_cast<int*>(p); }
@@ -866,12 +880,14 @@ class SolverImpl final : public SolverBase {
   double *trust_scale = nullptr;
   unsigned long long* solve_start = nullptr;          // tick at which each agent's current solve began (finite max_ms only)
   int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // per-agent trace of the last round ("debug")
-  unsigned long long* ladder_sync = nullptr; bool ladder_error_pending = false;   // rung agreement of the centralised backward pass (LadderSync)
+  unsigned long long* ladder_sync = nullptr;   // rung agreement of the centralised backward pass (LadderSync)
   int *active = nullptr, *alpha_sel = nullptr, *iters_solve = nullptr, *iters_total = nullptr, *exit_code = nullptr;
   long long *reg_events = nullptr, *counters = nullptr, *host_counters = nullptr;
-  CentralState *central = nullptr, *host_central = nullptr;
+  struct HostCentral { CentralState st; long long ladder_error; };     // what the commit kernel publishes per iteration of the stacked solve
+  CentralState* central = nullptr; HostCentral* host_central = nullptr;
   std::vector<void*> allocations;
   bool have_x0 = false, initialized = false, saved = false, last_total_valid = false, rollout_consistent = false;
+  bool controls_zero = false, saved_controls_zero = false;     // U is known to be all zeros (as set, never changed by a solve since)
   double central_total = 0.0;
   long long reg_base = 0;
   static constexpr int kMaxStampedLaunches = 1024;
