@@ -37,10 +37,12 @@ struct CentralState {
 __device__ inline double wave_serial_sum(const double* v, int n) {
   const int lane = static_cast<int>(threadIdx.x) & 63;
   double s = 0.0;
-  for (int base = 0; base < n; base += 64) {
-    const int a = base + lane;
-    const double x = a < n ? v[a] : -0.0;
-    MAS_UNROLL for (int i = 0; i < 64; ++i) s += __shfl(x, i);
+  for (int base = 0; base < n; base += 256) {                          // four loads in flight, then their 256 additions in order
+    double x[4];
+    MAS_UNROLL for (int q = 0; q < 4; ++q) { const int a = base + 64 * q + lane; x[q] = a < n ? v[a] : -0.0; }
+    MAS_UNROLL for (int q = 0; q < 4; ++q) {
+      if (base + 64 * q < n) { MAS_UNROLL for (int i = 0; i < 64; ++i) s += __shfl(x[q], i); }      // uniform
+    }
   }
   return s;
 }
