@@ -223,7 +223,7 @@ struct QuadRk4<Bicycle6> {
     const double ds = (s == 0) ? x[4] : hd;
     const double hv = x[3] + h * quad_from_prev(as);                    // v + h * (dv/dt of the stage below) = v + h * a_{s-1}
     const double vs = (s == 0) ? x[3] : hv;
-    const double kpsi = div_by(vs * mas_dt_tan(ds), make_inv_div(L));   // dynamics: d[2]
+    const double kpsi = div_by(vs * mas_dt_tan_onediv(ds), make_inv_div(L));   // dynamics: d[2]
     const double hp = x[2] + h * quad_from_prev(kpsi);
     const double psis = (s == 0) ? x[2] : hp;
     double sn, cs;

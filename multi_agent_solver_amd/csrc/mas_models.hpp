@@ -240,7 +240,7 @@ struct Bicycle6 : NoConstraints {
     const double psi = x[2], v = x[3], delta = x[4], a = x[5], L = P.p[6];
     double sn, cs;
     mas_dt_sincos(psi, &sn, &cs);
-    d[0] = v * cs; d[1] = v * sn; d[2] = div_by(v * mas_dt_tan(delta), make_inv_div(L)); d[3] = a; d[4] = u[0]; d[5] = u[1];
+    d[0] = v * cs; d[1] = v * sn; d[2] = div_by(v * mas_dt_tan_onediv(delta), make_inv_div(L)); d[3] = a; d[4] = u[0]; d[5] = u[1];   // (mas_dt_tan_onediv == mas_dt_tan bit for bit, mas_dettrig.h)
   }
   MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
     const double x = s[0], y = s[1], vx = s[3], delta = s[4], a = s[5];

@@ -20,7 +20,8 @@ def dt(tmp_path_factory):
                    "void f_sincos(double x,double*s,double*c){mas_dt_sincos(x,s,c);}\n"
                    "void f_sin_v(const double*x,double*y,int n){for(int i=0;i<n;++i)y[i]=mas_dt_sin(x[i]);}\n"
                    "void f_cos_v(const double*x,double*y,int n){for(int i=0;i<n;++i)y[i]=mas_dt_cos(x[i]);}\n"
-                   "void f_tan_v(const double*x,double*y,int n){for(int i=0;i<n;++i)y[i]=mas_dt_tan(x[i]);}\n")
+                   "void f_tan_v(const double*x,double*y,int n){for(int i=0;i<n;++i)y[i]=mas_dt_tan(x[i]);}\n"
+                   "void f_tan1_v(const double*x,double*y,int n){for(int i=0;i<n;++i)y[i]=mas_dt_tan_onediv(x[i]);}\n")
     so = d / "libdt.so"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", f"-I{ROOT}", str(src), "-o", str(so), "-lm"])
     lib = C.CDLL(str(so))
@@ -63,3 +64,16 @@ def test_sincos_equals_separate_calls_bitwise(dt):
     for x in rng.uniform(-500, 500, 20000):
         dt.f_sincos(C.c_double(x), C.byref(s), C.byref(c))
         assert s.value == dt.f_sin(x) and c.value == dt.f_cos(x)
+
+
+def test_tan_with_one_division_is_tan_bitwise(dt):
+    """mas_dt_tan_onediv ((-c) / s in odd quadrants, one division of selected operands) against mas_dt_tan (-(c / s), a branch
+    between two divisions): the same bits in every quadrant, at both zeros, for subnormals and out-of-range arguments."""
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-10, 10, 2_000_000), rng.uniform(-1e5, 1e5, 200_000), rng.uniform(-1e-300, 1e-300, 1000),
+                         np.array([0.0, -0.0, 5e-324, -5e-324, np.pi / 4, -np.pi / 4, np.pi / 2, -np.pi / 2, 1.5707963267948966, 3.0, -3.0, 0.5, -0.5,
+                                   np.nan, np.inf, -np.inf, 1e9])])
+    a, b = _vec(dt, "f_tan_v", xs), _vec(dt, "f_tan1_v", xs)
+    fin = ~np.isnan(a)
+    assert np.array_equal(a.view(np.uint64)[fin], b.view(np.uint64)[fin])     # bit patterns, signs of zero included
+    assert np.array_equal(np.isnan(a), np.isnan(b))
