@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
   };
   store_x();
   request(opA);
-  double lbv = f.lb[ci], ubv = f.ub[ci];
+  double lbv = f.clamp ? f.lb[ci] : -INFINITY, ubv = f.clamp ? f.ub[ci] : INFINITY;
   MAS_VGPR64(lbv); MAS_VGPR64(ubv);
   double c = 0.0;
   auto step = [&](int t, const Operands& cur, Operands& next) {
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
       double kd = 0.0;
       MAS_UNROLL for (int q = 0; q < NX; ++q) kd += cur.K[q] * (x[q] - cur.xr[q]);
       ui = (cur.ur + alpha * cur.k) + kd;
-      if (f.clamp) { ui = (ubv < ui) ? ubv : ui; ui = (ui < lbv) ? lbv : ui; }
+      ui = (ubv < ui) ? ubv : ui; ui = (ui < lbv) ? lbv : ui;     // (-inf / +inf without input bounds: ForwardBody)
     }
     u[0] = quad_bcast<0>(ui); u[1] = quad_bcast<1>(ui);
     { unsigned o = sto_u; MAS_OPAQUE32(o); st_off(Ujt, o, ui); }
