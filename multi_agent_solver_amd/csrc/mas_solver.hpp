@@ -903,17 +903,34 @@ class SolverImpl final : public SolverBase {
   HostStats stats;
 };
 
+// The models are instantiated in TWO translation units that differ in ONE compiler option, the machine scheduler's strategy:
+//   mas_capi.hip        default strategy     single-track family (C2, C3), pendulum
+//   mas_models_ilp.hip  -mllvm -amdgpu-sched-strategy=max-ilp     identity LQR (C4), bicycle6 (C5)
+// Every kernel here runs about one wavefront per SIMD, where hiding latency inside the wavefront is all there is; the max-ILP
+// strategy does that better for the LDS-tile backward kernel and the six-state rollouts (C5 56.6 -> 54.1 ms, C4 18.5 -> 18.1 ms)
+// and worse for the single-track kernels (C3 6.04 -> 6.24 ms), results identical bit for bit (tools/exp/ab_variants.py).
+std::unique_ptr<SolverBase> make_solver_ilp(const ProblemDesc& desc, void* external_stream);      // mas_models_ilp.hip: models 2, 5
+#if defined(MAS_TU_MODELS_ILP)
+std::unique_ptr<SolverBase> make_solver_ilp(const ProblemDesc& desc, void* external_stream) {
+  switch (desc.model_id) {
+    case 2: return std::make_unique<SolverImpl<LqrIdentity>>(desc, external_stream);
+    case 5: return std::make_unique<SolverImpl<Bicycle6>>(desc, external_stream);
+    default: return nullptr;
+  }
+}
+#else
 inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* external_stream) {
   switch (desc.model_id) {
     case 1: return std::make_unique<SolverImpl<SingleTrack>>(desc, external_stream);
-    case 2: return std::make_unique<SolverImpl<LqrIdentity>>(desc, external_stream);
+    case 2: return make_solver_ilp(desc, external_stream);
     case 3: return std::make_unique<SolverImpl<Pendulum>>(desc, external_stream);
     case 4: return std::make_unique<SolverImpl<SingleTrackLane>>(desc, external_stream);
-    case 5: return std::make_unique<SolverImpl<Bicycle6>>(desc, external_stream);
+    case 5: return make_solver_ilp(desc, external_stream);
     case 6: return std::make_unique<SolverImpl<SingleTrackLimited>>(desc, external_stream);
     default: return nullptr;
   }
 }
+#endif
 
 inline bool model_dims(int model_id, int* nx, int* nu) {
   int a = 0, b = 0;
