@@ -429,6 +429,32 @@ template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
   return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
 }
+// LLT::solve(Identity) (llt_solve_identity, mas_lane.hpp) with its NU columns spread over the lanes of an agent's DPP row: lane l
+// solves for column l % 4 -- the same sequence of operations for every column, the unit vector's entries as data -- and the
+// columns are gathered by row broadcasts (lane c of the row holds column c).  Each entry is exactly what llt_solve_identity
+// computes; NU - 1 column solves less per lane (at NU = 4: ~75 of ~500 instructions of a backward step).
+template <int N, int... E>
+__device__ __forceinline__ void gather_inverse(const double* col, double* Inv, std::integer_sequence<int, E...>) {
+  ((Inv[E] = row_bcast<E / N>(col[E % N])), ...);                     // Inv[c * N + i] = column c, entry i
+}
+template <int N>
+__device__ __forceinline__ void llt_solve_identity_by_columns(const double* Lm, int c, double* Inv) {
+  double o[N];
+  MAS_UNROLL for (int i = 0; i < N; ++i) o[i] = (i == c) ? 1.0 : 0.0;
+  MAS_UNROLL for (int i = 0; i < N; ++i) {
+    const double a = 1.0 / Lm[i * N + i];
+    o[i] *= a;
+    const double b = o[i];
+    MAS_UNROLL for (int r = i + 1; r < N; ++r) o[r] -= b * Lm[i * N + r];
+  }
+  MAS_UNROLL for (int i = N - 1; i >= 0; --i) {
+    const double a = 1.0 / Lm[i * N + i];
+    double b = 0.0;
+    MAS_UNROLL for (int r = i + 1; r < N; ++r) b += Lm[i * N + r] * o[r];
+    o[i] = (o[i] - b) * a;
+  }
+  gather_inverse<N>(o, Inv, std::make_integer_sequence<int, N * N>{});
+}
 // q_uu entries from the pass-2 results of the LDS-tile kernel: entry e is item W0 + e, formed in round (W0 + e) / 16 by lane (W0 + e) % 16
 template <int W0, int R2, int... E>
 __device__ __forceinline__ void tile_gather_quu(const double (&res)[R2], double* quu, std::integer_sequence<int, E...>) {
@@ -1192,7 +1218,8 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_row_kernel(Dims d, Mode
           wave_sync();                                               // the pass-2 outputs before the reads below
         }
       }
-      llt_solve_identity<NU>(Lfac, ninv);
+      if constexpr (NU > 2) llt_solve_identity_by_columns<NU>(Lfac, i < NU ? i : NU - 1, ninv);   // lane (i, j) solves column i
+      else llt_solve_identity<NU>(Lfac, ninv);
       MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];
       MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qu[q]; });
       MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
@@ -1413,7 +1440,8 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
     }
     double* kff_t = kff + static_cast<size_t>(t) * NU * d.Np;
     double* Kfb_t = Kfb + static_cast<size_t>(t) * NU * NX * d.Np;
-    llt_solve_identity<NU>(Lfac, ninv);
+    if constexpr (NU > 2) llt_solve_identity_by_columns<NU>(Lfac, i < NU ? i : NU - 1, ninv);   // lane (i, j) solves column i
+    else llt_solve_identity<NU>(Lfac, ninv);
     MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];
     MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * f.qu[q]; });
     MAS_UNROLL for (int m = 0; m < NU; ++m) { unsigned o = goff[m]; MAS_OPAQUE32(o); st_off(kff_t, o, kf[m]); }
