@@ -20,7 +20,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
 EXPORTS = [
     "mas_hip_abi_version", "mas_hip_device_count", "mas_hip_model_dims", "mas_hip_model_default_params",
     "mas_hip_create", "mas_hip_create_on_stream", "mas_hip_destroy", "mas_hip_last_error",
-    "mas_hip_set_param", "mas_hip_check_params",
+    "mas_hip_set_param", "mas_hip_check_params", "mas_hip_set_option",
     "mas_hip_set_initial_states_host", "mas_hip_set_controls_host",
     "mas_hip_set_initial_states_device", "mas_hip_set_controls_device",
     "mas_hip_initialize_problem", "mas_hip_save_initial", "mas_hip_restore_initial",
@@ -92,6 +92,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     lib.mas_hip_destroy.argtypes = [vp]
     lib.mas_hip_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     lib.mas_hip_check_params.argtypes = [vp]
+    lib.mas_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mas_hip_set_initial_states_host.argtypes = [vp, d]
     lib.mas_hip_set_controls_host.argtypes = [vp, d]
     lib.mas_hip_set_initial_states_device.argtypes = [vp, vp]

@@ -84,6 +84,10 @@ class BatchSolver:
             msg = self._lib.mas_hip_last_error(self._h)
             raise _capi.MasHipError(rc, msg.decode() if msg else "")
 
+    def set_option(self, key: str, value: int):
+        """choose between bit-identical kernel forms (include/mas_hip.h: mas_hip_set_option); results never depend on it"""
+        self._check(self._lib.mas_hip_set_option(self._h, key.encode(), int(value)))
+
     # -- parameters (iLQR::set_params, ilqr.hpp:39-55) ------------------------------------
     def set_params(self, params: dict):
         for key in ("max_iterations", "tolerance", "max_ms"):

@@ -184,6 +184,18 @@ struct BackwardBody {
   }
 };
 
+// Read-back of a round's counters: the commit is the last kernel of a round and runs after select has finished counting, so its
+// first lane copies the counter pair (or the stacked solve's state) into host-visible pinned memory -- a copy engine / copy
+// kernel per round (hipMemcpyAsync: ~4 us of kernel + ~6 us of gap in the trace) would sit on every round's critical path.
+struct Publish {
+  const long long* src = nullptr; long long* host = nullptr; int words = 0;
+  const int* flag = nullptr;        // optional: one more word, host[words] = *flag (the centralised pass's "gave up waiting" flag)
+  MAS_HD void operator()() const {
+    for (int i = 0; i < words; ++i) host[i] = src[i];
+    if (flag) host[words] = static_cast<long long>(*flag);
+  }
+};
+
 // -------------------------------------------------------------------------------------------
 // Speculative line search (ilqr.hpp:195-228): one lane per (agent, alpha trial).  The
 // reference tries alpha = 1, 1/2, ... one after the other and stops at the first strict
@@ -200,8 +212,10 @@ struct ForwardBody {
   double* trial_obj;     // [NA][Np] objective of each trial (== merit without constraint functions; may be null then)
   const int* active;
   ALView al;
+  Publish publish{};     // fused rounds (mas_fused_hip.hpp): the first lane publishes the counters of the select that ran in the kernel before
   MAS_HD void operator()(int a, int j) const {
     constexpr int NX = M::NX, NU = M::NU;
+    if (a == 0 && j == 0 && publish.host) publish();
 #if defined(__HIP_DEVICE_COMPILE__)
     // A wavefront with at least one active agent rolls out ALL its 64 agents: a retired agent's lane costs nothing
     // extra (SIMD), its results go to its own unused trial slots and trial_merit entry (SelectBody ignores inactive
@@ -298,6 +312,7 @@ struct SelectBody {
   unsigned long long* solve_start = nullptr; double max_ms = 0.0;
   int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // "debug" trace: iteration number (0 = idle) and d_merit per agent
   int* ended = nullptr;                // non-null: 1 for every agent whose solve ended in this iteration, else 0 (chained trust-region epilogue)
+  int* slot_out = nullptr;             // non-null (with next_list): slot_out[a] = the agent's position in next_list (fused rounds: where its trial column lies)
   MAS_HD bool out_of_time(int a) const {
     if (!solve_start) return false;
     const double elapsed_ms = static_cast<double>(static_cast<long long>(static_cast<double>(MAS_NOW_TICKS() - solve_start[a]) / kTicksPerMs));
@@ -355,8 +370,9 @@ struct SelectBody {
     }
     return kStillActive;
   }
-  MAS_HD void operator()(int a) const {
-    const int r = decide(a);
+  MAS_HD void operator()(int a) const { count(decide(a), a); }
+  // counters + compaction for outcome r of agent a (a whole wavefront calls this; lanes without an agent pass kIdle)
+  MAS_HD void count(int r, int a) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     // one atomic per wavefront and counter; the returned base gives every still-active agent its slot in the
     // compacted list that the next iteration's sweep walks
@@ -369,28 +385,20 @@ struct SelectBody {
       int base = 0;
       if (lane == leader) base = atomicAdd(n_active, __popcll(still));
       base = __shfl(base, leader);
-      if (next_list && goes_on) next_list[base + __popcll(still & ((1ull << lane) - 1ull))] = a;
+      if (next_list && goes_on) {
+        const int pos = base + __popcll(still & ((1ull << lane) - 1ull));
+        next_list[pos] = a;
+        if (slot_out) slot_out[a] = pos;
+      }
     }
 #else
     if ((r & ~kChained) == kConverged) MAS_ATOMIC_ADD_I64(n_converged, 1LL);
-    if (r == kStillActive || (r & kChained) != 0) { if (next_list) next_list[*n_active] = a; MAS_ATOMIC_ADD_INT(n_active, 1); }
+    if (r == kStillActive || (r & kChained) != 0) { if (next_list) { next_list[*n_active] = a; if (slot_out) slot_out[a] = *n_active; } MAS_ATOMIC_ADD_INT(n_active, 1); }
 #endif
   }
 };
 
-// copy the accepted trial into the current trajectory (x = best_x; u = best_u, ilqr.hpp:231-232)
-// Read-back of a round's counters: the commit is the last kernel of a round and runs after select has finished counting, so its
-// first lane copies the counter pair (or the stacked solve's state) into host-visible pinned memory -- a copy engine / copy
-// kernel per round (hipMemcpyAsync: ~4 us of kernel + ~6 us of gap in the trace) would sit on every round's critical path.
-struct Publish {
-  const long long* src = nullptr; long long* host = nullptr; int words = 0;
-  const int* flag = nullptr;        // optional: one more word, host[words] = *flag (the centralised pass's "gave up waiting" flag)
-  MAS_HD void operator()() const {
-    for (int i = 0; i < words; ++i) host[i] = src[i];
-    if (flag) host[words] = static_cast<long long>(*flag);
-  }
-};
-
+// copy the accepted trial into the current trajectory (x = best_x; u = best_u, ilqr.hpp:231-232); Publish: see above ForwardBody
 template <class M>
 struct CommitBody {
   Dims d;
@@ -480,8 +488,10 @@ struct BeginSolveBody {
   int* live_list = nullptr; int* live_count = nullptr; int n_agents = 0;   // every agent is active: identity list
   int* solves_left = nullptr; int chained = 0;                 // further solves every agent runs back to back after this one
   unsigned long long* solve_start = nullptr;                   // non-null: finite max_ms, stamp the start of the solve (ilqr.hpp:61)
+  int* slot_of = nullptr;                                      // non-null: position of every agent in the identity list (fused rounds)
   MAS_HD void operator()(int a) const {
     active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1;
+    if (slot_of) slot_of[a] = a;
     if (solve_start) solve_start[a] = MAS_NOW_TICKS();
     if (solves_left) solves_left[a] = chained;
     if (merit) merit[a] = cost[a];

@@ -90,6 +90,10 @@ int mas_hip_set_param(mas_hip_solver* h, const char* key, double value) {
   if (!key) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) { s.set_param(key, value); });
 }
+int mas_hip_set_option(mas_hip_solver* h, const char* key, int64_t value) {
+  if (!key) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) { if (!s.set_option(key, value)) throw std::invalid_argument(std::string("unknown option or value: ") + key); });
+}
 int mas_hip_check_params(const mas_hip_solver* h) {
   if (!h || !h->impl) return MAS_HIP_ERR_INVALID;
   if (!h->impl->params_complete()) { h->impl->last_error = "SolverParams lacks max_iterations, tolerance or max_ms (iLQR::set_params uses params.at())"; return MAS_HIP_ERR_INVALID; }

@@ -1,0 +1,424 @@
+// mas_fused_hip.hpp -- one iLQR round in TWO kernels for the four-state models (HIP build only).
+//
+// The unfused round is five launches on every agent's critical path:
+//     sweep (27 us) -> backward (86) -> line search (96) -> select (5) -> commit (9)            [C3, DESIGN.md section 4]
+// although only the two chains in the middle are inherently serial.  Here a round is
+//     mas_linearise_riccati_kernel  ->  line search
+// and the first kernel does, per workgroup of 16 consecutive agents,
+//   phase 0   select of the PREVIOUS round for its 16 agents (SelectBody: acceptance, termination, counters, next live list)
+//   helpers   HELPERS wavefronts linearise the workgroup's (agent, t) items in REVERSE time, four time steps of the 16 agents per
+//             wavefront pass (lane = (agent, dt)), and hand the derivative tiles to the backward wavefronts through a ring of
+//             RING chunk slots in LDS -- the tiles (46 KB per agent and iteration, 90 % of the unfused sweep's HBM traffic and all
+//             of the backward pass's reads) never leave the CU.  The same lanes commit the trial the select accepted: they read
+//             x_t, u_t from the trial plane and store them to X, U (ilqr.hpp:231-232) while they linearise there.
+//   backward  four wavefronts (4 agents each, 16 lanes per agent = one DPP row = the 4 x 4 value Hessian) walk the Riccati
+//             recursion of mas_backward_row_kernel, tile operands from the LDS ring instead of HBM.
+// The linearisation of step t only needs the committed trajectory, the recursion consumes tiles last step first, and a lone
+// backward wavefront leaves two thirds of its SIMD's issue slots empty (profiles/r2_sq_counters_c3.json): the helpers'
+// ~1,500 FP64 instructions per item run in those slots (s_setprio keeps the chain ahead of them).
+// Synchronisation is inside ONE workgroup: LDS words `ready[slot]` (helper -> backward) and `consumed[wave]` (backward ->
+// helper), written behind s_waitcnt lgkmcnt(0); no global flags, no cross-CU visibility rules.  Every wait is bounded.
+// Arithmetic: linearise<M>, SelectBody::decide and the recursion are the very functions / statements of the unfused kernels, so
+// every result is bit-identical (tests/test_gpu_parity.py compares both forms with each other and with the oracle).
+#pragma once
+
+#include "mas_kernels_hip.hpp"
+
+namespace mas {
+
+struct FusedRound {
+  SelectBody sel;                 // the previous round's select (do_select != 0)
+  int do_select = 0;
+  const double* Xs = nullptr;     // trial planes of the previous round's line search
+  const double* Us = nullptr;
+  int planes_by_slot = 0;         // those planes are indexed by the agent's slot in that round's live list (mas_forward_quad_kernel)
+  const int* slot_prev = nullptr; // [Np] that slot
+  double* D_dump = nullptr;       // staged access (parity tests): the tiles also go to the global tile array
+  int* error = nullptr;           // raised when a bounded wait gives up
+};
+
+constexpr int kFusedAgents = 16;            // agents per workgroup: four backward wavefronts of four agents
+constexpr int kFusedSpinLimit = 1 << 22;
+
+// LDS control words of a workgroup
+struct FusedCtl {
+  int ready[4];                  // ready[s] = n + 1 once chunk n lies complete in ring slot s = n % RING
+  int consumed[4];               // chunks backward wavefront w has finished reading (its data has arrived)
+  int act[kFusedAgents], selj[kFusedAgents], col[kFusedAgents];
+  int any_act, any_pend, pad0, pad1;
+};
+
+template <class M, int HELPERS, int RING>
+struct FusedLayout {
+  using L = DerivLayout<M>;
+  static constexpr int ND = L::ND;
+  static constexpr int TS = ND | 1;                               // tile stride in the ring (odd: the 16 lanes of a ds_write_b64 group hit distinct banks)
+  static constexpr int kBwdStride = 112;                          // per-agent scratch of the recursion (mas_backward_row_kernel)
+  static constexpr int oBwd = 0, oRing = oBwd + kFusedAgents * kBwdStride, oCtl = oRing + RING * 64 * TS;
+  static constexpr size_t kBytes = sizeof(double) * oCtl + sizeof(FusedCtl);
+  static constexpr int kThreads = 64 * (4 + HELPERS);
+};
+
+// one LDS word, re-read until `done(value)`; uniform over the wavefront
+template <class Pred>
+__device__ __forceinline__ bool lds_wait(const volatile int* word, Pred done, int* error) {
+  int spins = 0;
+  for (;;) {
+    const int v = __builtin_amdgcn_readfirstlane(*word);
+    if (done(v)) return true;
+    ++spins;
+    if (spins > kFusedSpinLimit) { if ((threadIdx.x & 63) == 0 && error) atomicExch(error, 1); return false; }   // ~0.2 s
+    if ((spins & 4095) == 0 && error && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;   // somebody gave up already
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// ---- the recursion of one backward wavefront (4 agents, 16 lanes each): mas_backward_row_kernel's step, operands from the LDS ring --
+template <class M, int HELPERS, int RING>
+__device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelParams& P, double* __restrict__ lds, FusedCtl* ctl,
+                                                    int wave, int a_base, const double* __restrict__ xT_src, unsigned xT_col,
+                                                    double* __restrict__ kff, double* __restrict__ Kfb, long long* __restrict__ reg_events, int* error) {
+  using FL = FusedLayout<M, HELPERS, RING>;
+  using L = DerivLayout<M>;
+  constexpr int NX = 4, NU = M::NU, TS = FL::TS;
+  static_assert(M::NX == 4 && NU >= 1 && NU <= 4, "one DPP row = the 4 x 4 value Hessian");
+  constexpr int LPA = 16, LL = 16;
+  constexpr int oAtV = 0, oBtV = 16, oQxx = 32, oQux = 48, oL = 64, oVx = 80, oQx = 84, oPad = 96;
+  constexpr bool kMerged = NU <= 2;
+  constexpr bool kRung0First = M::kAnalyticLuu;
+  constexpr bool kFactorByPermute = NU <= 2;
+
+  const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane;
+  const int i = lane & 3, j = lane >> 2, iu = (i < NU) ? i : NU - 1, ju = (j < NU) ? j : NU - 1;
+  const int al = wave * 4 + slot, a = a_base + al;
+  const bool valid = ctl->act[al] != 0;
+  double* T = lds + FL::oBwd + al * FL::kBwdStride;
+  const double* ring = lds + FL::oRing;
+  auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+  // terminal boundary condition, ilqr.hpp:92-102: lane 0 evaluates it, every lane picks up its own entries
+  if (lane == 0) {
+    double xT[NX], vx[NX], vxx[NX * NX];
+    MAS_UNROLL for (int q = 0; q < NX; ++q) xT[q] = valid ? (xT_src + (static_cast<size_t>(d.T) * NX + q) * d.Np)[xT_col] : 0.0;
+    terminal_boundary<M>(xT, vx, vxx, P);
+    MAS_UNROLL for (int q = 0; q < NX; ++q) T[oVx + q] = vx[q];
+    MAS_UNROLL for (int q = 0; q < NX * NX; ++q) T[oQxx + q] = vxx[q];
+  }
+  wave_sync();
+  double Vown = T[oQxx + lane], vxi = T[oVx + i];
+  wave_sync();
+
+  // this lane's operands of one tile: element indices (the ring holds plain tiles, TS doubles apart)
+  int eAi = L::oA + 4 * i, eAj = L::oA + 4 * j, eBi = L::oB + 4 * iu, eBj = L::oB + 4 * ju;
+  int elx = L::oLx + i, elu = L::oLu + iu, elxx = L::oLxx + lane, elux = L::oLux + iu + NU * j, eluu = L::oLuu + iu + NU * ju;
+  // merged second round of pass 2 (NU <= 2), see mas_backward_row_kernel
+  const int item2 = (i < NU) ? 0 : ((i >= 2 && j < NU && i - 2 < NU) ? 1 : ((i >= 2 && j >= 2) ? 2 : 3));
+  const int c2 = (i - 2) + 2 * (j - 2);
+  int r_row2 = oBtV + iu * 4;
+  if constexpr (kMerged) {
+    if (item2 == 0) { eBj = eAj; }
+    else if (item2 == 1) { eBj = L::oB + 4 * j; elux = L::oLuu + (i - 2) + NU * j; r_row2 = oBtV + (i - 2) * 4; }
+    else if (item2 == 2) { eBj = L::oA + 4 * c2; elux = L::oLx + c2; r_row2 = oVx; }
+    else { eBj = eAj; r_row2 = oBtV; }
+  }
+  struct Tile { double Ai[NX], Aj[NX], Bi[NX], Bj[NX]; double lx, lu, lxx, lux, luu; };
+  const int C = (d.T + 3) >> 2;                                        // chunks of four time steps
+  // tile of step t: chunk n = C-1 - t/4 (the order the helpers produce them in), ring slot n % RING, tile (t & 3) * 16 + agent
+  auto fetch = [&](Tile& o, int t) {
+    const int n = C - 1 - (t >> 2);
+    const double* tile = ring + (static_cast<size_t>(n % RING) * 64 + static_cast<size_t>(t & 3) * 16 + al) * TS;
+    MAS_UNROLL for (int k = 0; k < NX; ++k) { o.Ai[k] = tile[eAi + k]; o.Aj[k] = tile[eAj + k]; o.Bi[k] = tile[eBi + k]; o.Bj[k] = tile[eBj + k]; }
+    o.lu = tile[elu]; o.lxx = tile[elxx]; o.lux = tile[elux];
+    if constexpr (!kMerged) { o.lx = tile[elx]; o.luu = tile[eluu]; }
+  };
+  auto acquire = [&](int t) {                                          // the chunk of step t lies complete in its slot
+    const int n = C - 1 - (t >> 2);
+    lds_wait(&ctl->ready[n % RING], [n](int v) { return v >= n + 1; }, error);
+  };
+  long long regs = 0;
+  double rung_add[LL - 1];
+  {
+    double reg = 1e-6;
+    MAS_UNROLL for (int q = 0; q < LL - 1; ++q) { rung_add[q] = (q < rung_lane) ? reg : -0.0; reg *= 10.0; }
+  }
+  unsigned goff[NU], koff[NU];
+  MAS_UNROLL for (int m = 0; m < NU; ++m) goff[m] = static_cast<unsigned>((static_cast<size_t>(m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int m = 0; m < NU; ++m) koff[m] = static_cast<unsigned>((static_cast<size_t>(i * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  double* kff_t = kff + static_cast<size_t>(d.T - 1) * NU * d.Np;
+  double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
+  const int w_atv = oAtV + i * 4 + j, w_btv = (i < NU) ? (oBtV + i * 4 + j) : (oPad + lane);
+  const int w_qux = (i < NU) ? (oQux + j * NU + i) : ((kMerged && item2 == 2) ? (oQx + c2) : (oPad + lane));
+  const int w_vx = (j == 0) ? (oVx + i) : (oPad + lane);
+
+  Tile tA, tB;
+  acquire(d.T - 1);
+  fetch(tA, d.T - 1);
+  auto step = [&](int t, const Tile& c, Tile& nx) {
+    MAS_UNROLL for (int m = 0; m < NU; ++m) { MAS_OPAQUE32(goff[m]); MAS_OPAQUE32(koff[m]); }
+    if (t > 0) {
+      if (((t - 1) & 3) == 3) acquire(t - 1);                          // uniform: the next tile opens a new chunk
+      fetch(nx, t - 1);
+    }
+    const double* Ai = c.Ai; const double* Aj = c.Aj; const double* Bi = c.Bi; const double* Bj = c.Bj;
+
+    // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
+    double qx_i, qu_own;
+    {
+      const double Vc[NX] = {quad_bcast<0>(Vown), quad_bcast<1>(Vown), quad_bcast<2>(Vown), quad_bcast<3>(Vown)};   // V(k, j)
+      const double vxk[NX] = {row_bcast<0>(vxi), row_bcast<1>(vxi), row_bcast<2>(vxi), row_bcast<3>(vxi)};         // v_x(k)
+      double s;
+      s = sum_terms<NX>([&](int k) { return Ai[k] * Vc[k]; });
+      T[w_atv] = s;
+      s = sum_terms<NX>([&](int k) { return Bi[k] * Vc[k]; });
+      T[w_btv] = s;
+      if constexpr (!kMerged) {
+        s = sum_terms<NX>([&](int k) { return Ai[k] * vxk[k]; });
+        qx_i = c.lx + s;
+      }
+      s = sum_terms<NX>([&](int k) { return Bi[k] * vxk[k]; });
+      qu_own = c.lu + s;
+    }
+    wave_sync();
+    // the tile requested above has arrived with this wait: if it was the last of its chunk, the helpers may reuse the slot
+    if (t > 0 && ((t - 1) & 3) == 0 && tid == 0) ctl->consumed[wave] = C - ((t - 1) >> 2);
+    // ---- pass 2 (second factors of ilqr.hpp:117-119)
+    double quu[NU * NU], qu[NU], quxj[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU], qxx_own;
+    {
+      double ra[NX], rb[NX];
+      MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
+      double s;
+      s = sum_terms<NX>([&](int k) { return ra[k] * Aj[k]; });
+      qxx_own = c.lxx + s;
+      T[oQxx + lane] = qxx_own;
+      if constexpr (kMerged) {
+        s = sum_terms<NX>([&](int k) { return rb[k] * Bj[k]; });          // this lane's second-round item
+        const double item = c.lux + s;
+        T[w_qux] = item;
+        row_gather_block_at<NU, 2>(item, quu, std::make_integer_sequence<int, NU * NU>{});   // q_uu(m, n) from lane (2 + m, n)
+        quad_gather(item, quxj, std::make_integer_sequence<int, NU>{});
+      } else {
+        s = sum_terms<NX>([&](int k) { return rb[k] * Aj[k]; });
+        const double qux_own = c.lux + s;
+        s = sum_terms<NX>([&](int k) { return rb[k] * Bj[k]; });
+        const double quu_own = c.luu + s;
+        T[w_qux] = qux_own;
+        row_gather_block_at<NU, 0>(quu_own, quu, std::make_integer_sequence<int, NU * NU>{});
+        quad_gather(qux_own, quxj, std::make_integer_sequence<int, NU>{});
+      }
+      row_gather_first(qu_own, qu, std::make_integer_sequence<int, NU>{});
+    }
+    // ---- pass 3 (ilqr.hpp:172-192)
+    {
+      {
+        double cur[NU * NU];
+        MAS_UNROLL for (int e = 0; e < NU * NU; ++e) cur[e] = quu[e];
+        int win = -1;
+        bool rung0_everywhere = false;
+        if constexpr (kRung0First) {
+          MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = cur[e];
+          const int ok0 = llt_compute_straight<NU>(Lfac) == 0;
+          rung0_everywhere = __ballot(ok0 || !valid) == ~0ull;
+          if (rung0_everywhere) win = 0;
+        }
+        if (!rung0_everywhere) {
+          MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
+            MAS_UNROLL for (int e = 0; e < NU; ++e) cur[e * NU + e] += rung_add[q];
+          }
+          {
+            MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = cur[e];
+            const int ok = llt_compute_straight<NU>(Lfac) == 0;
+            const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (field != 0u) win = __builtin_ctz(field);
+          }
+          if (__ballot(win < 0) != 0ull) {
+            double reg_next = 0.0;
+            int base = 0;
+            for (;;) {
+              if (win < 0 && base + LL > kRegLadderMax) win = base + LL - 1;
+              if (__ballot(win < 0) == 0ull) break;
+              if (win < 0) {
+                if (base == 0) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+                for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int e = 0; e < NU; ++e) cur[e * NU + e] += reg_next; reg_next *= 10.0; }
+                base += LL;
+              }
+              double Ltry[NU * NU];
+              MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Ltry[e] = cur[e];
+              const int ok = llt_compute<NU>(Ltry) == 0;
+              const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+              if (win < 0) {
+                MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = Ltry[e];
+                if (field != 0u) win = base + __builtin_ctz(field);
+              }
+            }
+          }
+          if (lane == 0) regs += win;
+          if constexpr (kFactorByPermute) {
+            const int src = ((tid & ~(LPA - 1)) + (win & (LL - 1))) * 4;
+            MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+              if (e % NU >= e / NU) {                                  // column-major: row >= column
+                const int lo32 = __builtin_amdgcn_ds_bpermute(src, __double2loint(Lfac[e])), hi32 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(Lfac[e]));
+                Lfac[e] = __hiloint2double(hi32, lo32);
+              }
+            }
+            wave_sync();                                               // the pass-2 outputs before the reads below
+          } else {
+            if (lane == (win & (LL - 1))) { MAS_UNROLL for (int e = 0; e < NU * NU; ++e) T[oL + e] = Lfac[e]; }
+            wave_sync();                                               // also orders the pass-2 outputs before the reads below
+            MAS_UNROLL for (int e = 0; e < NU * NU; ++e) Lfac[e] = T[oL + e];
+          }
+        } else {
+          wave_sync();                                                 // the pass-2 outputs before the reads below
+        }
+      }
+      if constexpr (NU > 2) llt_solve_identity_by_columns<NU>(Lfac, i < NU ? i : NU - 1, ninv);   // lane (i, j) solves column i
+      else llt_solve_identity<NU>(Lfac, ninv);
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) ninv[e] = -ninv[e];
+      MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qu[q]; });
+      MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
+      {
+        double quxi[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) quxi[m] = T[oQux + i * NU + m];
+        const double qxx_mir = T[oQxx + j + 4 * i];
+        if constexpr (kMerged) qx_i = T[oQx + i];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {
+          Ki[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxi[q]; });
+          Kj[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxj[q]; });
+        }
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {
+          ktqi[m] = sum_terms<NU>([&](int q) { return Ki[q] * quu[m * NU + q]; });
+          ktqj[m] = sum_terms<NU>([&](int q) { return Kj[q] * quu[m * NU + q]; });
+        }
+        double s, own, mir;
+        s = sum_terms<NU>([&](int m) { return Ki[m] * quxj[m]; });
+        own = qxx_own + s;
+        s = sum_terms<NU>([&](int m) { return quxi[m] * Kj[m]; });
+        own = own + s;
+        s = sum_terms<NU>([&](int m) { return ktqi[m] * Kj[m]; });
+        own = own + s;
+        s = sum_terms<NU>([&](int m) { return Kj[m] * quxi[m]; });
+        mir = qxx_mir + s;
+        s = sum_terms<NU>([&](int m) { return quxj[m] * Ki[m]; });
+        mir = mir + s;
+        s = sum_terms<NU>([&](int m) { return ktqj[m] * Ki[m]; });
+        mir = mir + s;
+        Vown = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));      // aliased in-place symmetrisation, :192
+        double vx_new;
+        s = sum_terms<NU>([&](int m) { return Ki[m] * qu[m]; });
+        vx_new = qx_i + s;
+        s = sum_terms<NU>([&](int m) { return quxi[m] * kf[m]; });
+        vx_new = vx_new + s;
+        s = sum_terms<NU>([&](int m) { return ktqi[m] * kf[m]; });
+        vxi = vx_new + s;
+        if constexpr (kMerged) T[w_vx] = vxi;                       // pass 2 of the next step reads v_x as an LDS row
+        MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[m], Ki[m]);
+      }
+    }
+    kff_t -= static_cast<size_t>(NU) * d.Np; Kfb_t -= static_cast<size_t>(NU) * NX * d.Np;
+  };
+  int t = d.T - 1;
+  for (; t >= 1; t -= 2) { step(t, tA, tB); step(t - 1, tB, tA); }
+  if (t == 0) step(0, tA, tB);
+  if (valid && lane == 0) reg_events[a] += regs;
+}
+
+// ---- one helper wavefront: commit + linearisation of the workgroup's items, chunk by chunk in reverse time ----
+template <class M, int HELPERS, int RING>
+__device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelParams& P, double* __restrict__ lds, FusedCtl* ctl, int h, int a_base,
+                                                  double* __restrict__ X, double* __restrict__ U, const FusedRound& fr) {
+  using FL = FusedLayout<M, HELPERS, RING>;
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, ND = L::ND, TS = FL::TS;
+  const int l = static_cast<int>(threadIdx.x) & 63, al = l & 15, dt = l >> 4, a = a_base + al;
+  const bool act = ctl->act[al] != 0;
+  const int jsel = ctl->selj[al];
+  const bool pend = jsel >= 0;
+  const bool any_act = ctl->any_act != 0;
+  // where this agent's trajectory lies: the trial plane its select accepted (column = agent or its slot in that round's list), else X, U
+  const double* Xsrc = pend ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * NX * d.Np : X;
+  const double* Usrc = pend ? fr.Us + static_cast<size_t>(jsel) * d.T * NU * d.Np : U;
+  const unsigned col = static_cast<unsigned>(ctl->col[al]);
+  double* ring = lds + FL::oRing;
+  const int C = (d.T + 3) >> 2;
+  for (int n = h; n < C; n += HELPERS) {
+    const int t = 4 * (C - 1 - n) + dt;
+    const bool in = t < d.T;
+    double x[NX], u[NU];
+    MAS_UNROLL for (int q = 0; q < NX; ++q) x[q] = 0.0;
+    MAS_UNROLL for (int q = 0; q < NU; ++q) u[q] = 0.0;
+    if (in && (act || pend)) {
+      MAS_UNROLL for (int q = 0; q < NX; ++q) x[q] = (Xsrc + (static_cast<size_t>(t) * NX + q) * d.Np)[col];
+      MAS_UNROLL for (int q = 0; q < NU; ++q) u[q] = (Usrc + (static_cast<size_t>(t) * NU + q) * d.Np)[col];
+    }
+    if (in && pend) {                                                  // x = best_x; u = best_u, ilqr.hpp:231-232
+      MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, t * NX + q, a) = x[q];
+      MAS_UNROLL for (int q = 0; q < NU; ++q) MAS_AT(U, t * NU + q, a) = u[q];
+      if (t == d.T - 1) { MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, d.T * NX + q, a) = (Xsrc + (static_cast<size_t>(d.T) * NX + q) * d.Np)[col]; }
+    }
+    if (!any_act) continue;                                            // uniform: a workgroup of retired agents only commits
+    double Dl[ND];
+    if (in && act) linearise<M>(x, u, t, Dl, P);
+    else { MAS_UNROLL for (int e = 0; e < ND; ++e) Dl[e] = 0.0; }
+    if (n >= RING) {                                                   // the slot's previous chunk has been read by all four backward wavefronts
+      MAS_UNROLL for (int w = 0; w < 4; ++w) lds_wait(&ctl->consumed[w], [n](int v) { return v >= n - RING + 1; }, fr.error);
+    }
+    double* tile = ring + (static_cast<size_t>(n % RING) * 64 + l) * TS;
+    MAS_UNROLL for (int e = 0; e < ND; ++e) tile[e] = Dl[e];
+    if (fr.D_dump && in && act) { MAS_UNROLL for (int e = 0; e < ND; ++e) MAS_TILE_AT(fr.D_dump, ND, t, a, e) = Dl[e]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (l == 0) ctl->ready[n % RING] = n + 1;
+  }
+}
+
+// grid = ceil(N / 16) workgroups of 64 * (4 + HELPERS) threads, FusedLayout::kBytes of dynamic LDS
+template <class M, int HELPERS, int RING>
+__global__ void __launch_bounds__(64 * (4 + HELPERS), 2)
+mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, double* __restrict__ U, double* __restrict__ kff, double* __restrict__ Kfb,
+                             long long* __restrict__ reg_events, FusedRound fr) {
+  using FL = FusedLayout<M, HELPERS, RING>;
+  static_assert(RING >= 2 && RING <= 4 && HELPERS >= 1, "ring of chunk slots");
+  extern __shared__ double lds[];
+  FusedCtl* ctl = reinterpret_cast<FusedCtl*>(lds + FL::oCtl);
+  const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
+  const int a_base = static_cast<int>(blockIdx.x) * kFusedAgents;
+
+  // ---- phase 0: the previous round's select for this workgroup's agents (wavefront 0, lanes 0..15)
+  if (wave == 0) {
+    const int a = a_base + lane;
+    const bool mine = lane < kFusedAgents && a < d.N;
+    if (fr.do_select) {                                                 // uniform
+      int r = SelectBody::kIdle;
+      if (mine) r = fr.sel.decide(a);
+      fr.sel.count(r, a);
+    }
+    int act = 0, jsel = -1;
+    if (mine) { act = fr.sel.active[a]; jsel = fr.sel.alpha_sel[a]; }
+    if (lane < kFusedAgents) {
+      ctl->act[lane] = act; ctl->selj[lane] = jsel;
+      ctl->col[lane] = (jsel >= 0 && fr.planes_by_slot) ? fr.slot_prev[a] : a;
+    }
+    const unsigned long long am = __ballot(act != 0), pm = __ballot(jsel >= 0);
+    if (lane == 0) { ctl->any_act = am != 0ull; ctl->any_pend = pm != 0ull; }
+    if (lane < 4) { ctl->ready[lane] = 0; ctl->consumed[lane] = 0; }
+  }
+  __syncthreads();
+  const bool any_act = ctl->any_act != 0, any_pend = ctl->any_pend != 0;
+  if (!any_act && !any_pend) return;
+
+  if (wave < 4) {
+    if (!any_act) return;
+    const int al0 = wave * 4 + (lane >> 4);
+    if (__ballot(ctl->act[al0] != 0) == 0ull) {                       // none of this wavefront's four agents is active: the helpers never wait for it
+      if (lane == 0) ctl->consumed[wave] = 0x7fffffff;
+      return;
+    }
+    __builtin_amdgcn_s_setprio(3);                                     // the chain goes first; the helpers fill the issue slots it leaves
+    const int jsel = ctl->selj[al0];
+    const double* xT_src = (jsel >= 0) ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * M::NX * d.Np : X;
+    fused_backward_wave<M, HELPERS, RING>(d, P, lds, ctl, wave, a_base, xT_src, static_cast<unsigned>(ctl->col[al0]), kff, Kfb, reg_events, fr.error);
+  } else {
+    __builtin_amdgcn_s_setprio(0);
+    fused_helper_wave<M, HELPERS, RING>(d, P, lds, ctl, wave - 4, a_base, X, U, fr);
+  }
+}
+
+}  // namespace mas

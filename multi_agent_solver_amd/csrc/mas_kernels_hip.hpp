@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(256) mas_forward_quad_kernel(const ForwardBody
   static_assert((NX == 4 || NX == 6) && NU == 2, "state components per lane of the quad (QuadStore), one control per lane pair");
   const Dims d = f.d;
   const int tid = static_cast<int>(threadIdx.x), s = tid & 3, ci = s & 1;
+  if (f.publish.host && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) f.publish();   // fused rounds: counters of the select that ran in the kernel before
   const int n_live = live_count ? *live_count : d.N;                   // uniform
   const int slot0 = (static_cast<int>(blockIdx.x) * 64 + (tid >> 6) * 16);
   if (slot0 >= n_live) return;                                         // wave-uniform

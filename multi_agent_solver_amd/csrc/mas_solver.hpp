@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <limits>
 #include <memory>
@@ -22,6 +23,7 @@
 #include "mas_dense.hpp"
 #if !defined(MAS_HOST_EMULATION)
 #include "mas_kernels_hip.hpp"
+#include "mas_fused_hip.hpp"
 #endif
 
 namespace mas {
@@ -82,6 +84,47 @@ class SolverBase {
   CostExchange cost_exchange = nullptr;
   void* cost_exchange_ctx = nullptr;
 
+  // Which of several BIT-IDENTICAL kernel forms a launch uses (tests hold the forms against each other; tools/ measures them).
+  // Defaults are the measured best.  Set through mas_hip_set_option; a build with -DMAS_HIP_ENV_SWITCHES (experiments only,
+  // never the product build) also reads MAS_HIP_<KEY> from the environment, once, when the handle is created.
+  struct KernelForms {
+    bool fused = true;                      // two-kernel rounds for the four-state models (mas_fused_hip.hpp)
+    long long forward_quad_max = 1600;      // four-lanes-per-rollout line search up to this many live agents (0: never)
+    bool backward_tile = false;             // the LDS-tile backward kernel also for NX == 4
+    bool backward_list = true;              // the LDS-tile kernel walks the round's list of live agents
+    bool central_pipeline = true;           // centralised backward pass with the speculative step
+    bool central_one_xcd = true;            // its working workgroups on one XCD
+    bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
+    int central_combine = 1, central_wpb = kCentralWavesPerBlock;
+    bool set(const std::string& key, long long v) {
+      if (key == "fused") fused = v != 0;
+      else if (key == "forward_quad_max") forward_quad_max = v;
+      else if (key == "backward_tile") backward_tile = v != 0;
+      else if (key == "backward_list") backward_list = v != 0;
+      else if (key == "central_pipeline") central_pipeline = v != 0;
+      else if (key == "central_one_xcd") central_one_xcd = v != 0;
+      else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
+      else if (key == "central_combine") central_combine = static_cast<int>(v);
+      else if (key == "central_wpb") { if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) central_wpb = static_cast<int>(v); else return false; }
+      else return false;
+      return true;
+    }
+    void from_env() {
+#if defined(MAS_HIP_ENV_SWITCHES)
+      static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "central_pipeline", "central_one_xcd",
+                                   "force_single_workgroup_central", "central_combine", "central_wpb"};
+      for (const char* k : keys) {
+        std::string name = "MAS_HIP_";
+        for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        if (const char* e = std::getenv(name.c_str())) set(k, std::atoll(e));
+      }
+#endif
+    }
+  };
+  KernelForms switches;
+  bool set_option(const std::string& key, long long v) { const bool ok = switches.set(key, v); on_option_changed(); return ok; }
+  virtual void on_option_changed() {}
+
   Backend be;
   std::string last_error;
   // defaults of the iLQR constructor, ilqr.hpp:26-37
@@ -100,6 +143,7 @@ template <class M>
 class SolverImpl final : public SolverBase {
   static constexpr int NX = M::NX, NU = M::NU;
   static constexpr bool kConstrained = (M::NEQ + M::NIN) > 0;
+  static constexpr bool kFusable = NX == 4 && !kConstrained;     // the two-kernel round of mas_fused_hip.hpp
   using L = DerivLayout<M>;
 
  public:
@@ -124,6 +168,7 @@ class SolverImpl final : public SolverBase {
     cost = dalloc(Np); merit = dalloc(Np);
     x0_saved = dalloc(NX * Np); U_saved = dalloc(static_cast<size_t>(T) * NU * Np);
     live_lists[0] = ialloc(Np); live_lists[1] = ialloc(Np); live_count0 = ialloc(16); solves_left = ialloc(Np);
+    slot_of[0] = ialloc(Np); slot_of[1] = ialloc(Np); fused_error = ialloc(16);
     active = ialloc(Np); alpha_sel = ialloc(Np); iters_solve = ialloc(Np); iters_total = ialloc(Np); exit_code = ialloc(Np);
     reg_events = static_cast<long long*>(raw_alloc(sizeof(long long) * Np));
     counters = static_cast<long long*>(raw_alloc(sizeof(long long) * 32));
@@ -138,6 +183,9 @@ class SolverImpl final : public SolverBase {
     stage = dalloc(stage_elems);
     host_counters = static_cast<long long*>(be.alloc_pinned(sizeof(long long) * 32));
     host_central = static_cast<HostCentral*>(be.alloc_pinned(2 * sizeof(HostCentral)));   // two read-back slots (the centralised loop runs one iteration ahead)
+    std::memset(host_counters, 0, sizeof(long long) * 32);      // hipHostMalloc does not zero: a word the device never writes
+    std::memset(host_central, 0, 2 * sizeof(HostCentral));      // (the ladder's give-up flag without a ladder) must read 0
+    switches.from_env();
     be.sync();
   }
   ~SolverImpl() override {
@@ -404,8 +452,22 @@ class SolverImpl final : public SolverBase {
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
     { std::vector<long long> rg(d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N); for (auto v : rg) reg_base += v; }   // keep the running statistics
     be.zero(reg_events, sizeof(long long) * d.Np);
-    launch_sweep(0.0);
-    launch_backward(0.0);
+    bool staged_fused = false;
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (kFusable) {
+      if (fused_enabled()) {            // the product's form of sweep + backward: the fused kernel, its tiles also dumped to the tile array
+        FusedRound fr;
+        fr.sel = SelectBody{}; fr.sel.active = active; fr.sel.alpha_sel = alpha_sel;
+        fr.do_select = 0; fr.Xs = Xs; fr.Us = Us; fr.slot_prev = slot_of[0]; fr.D_dump = D; fr.error = fused_error;
+        launch_fused(fr, 0.0);
+        staged_fused = true;
+      }
+    }
+#endif
+    if (!staged_fused) {
+      launch_sweep(0.0);
+      launch_backward(0.0);
+    }
     if (derivs) { be.template launch_2d<4>("tiles_to_host", TilesToHostBody{d, L::ND, D, stage}, d.N, d.T); download(derivs, static_cast<size_t>(d.N) * d.T * L::ND, false); }
     if (ko) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, kff, stage, d.T}, d.N, d.T); download(ko, static_cast<size_t>(d.N) * d.T * NU, false); }
     if (Ko) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU * NX, Kfb, stage, d.T}, d.N, d.T); download(Ko, static_cast<size_t>(d.N) * d.T * NU * NX, false); }
@@ -540,8 +602,7 @@ class SolverImpl final : public SolverBase {
   // 1600 slots x 10 trials x 4 lanes = 1000 wavefronts: the most the quad form can spread one per SIMD (1024 on MI355X);
   // beyond that its wavefronts double up and the one-lane form (640 wavefronts at 4096 agents) is faster again
   long long quad_forward_max_slots() const {
-    if (const char* e = std::getenv("MAS_HIP_FORWARD_QUAD_MAX")) return std::atoll(e);     // experiments / tests: 0 = never, large = always
-    return 1600;
+    return switches.forward_quad_max;
   }
   // backward pass of the stacked problem: the 16-lane tile kernel with the rung agreement across all wavefronts
   // (LadderSync); constrained models and the host emulation keep the one-workgroup body
@@ -553,7 +614,7 @@ class SolverImpl final : public SolverBase {
       if (!ladder_sync) ladder_sync = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * (words + 2)));
       MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
       LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
-      if (const char* e = std::getenv("MAS_HIP_CENTRAL_COMBINE")) sy.combine = std::atoi(e);
+      sy.combine = switches.central_combine;
       constexpr int apw = 64 / kBackwardLanesPerAgent;
       be.begin("central_backward", bytes);
       const int wpb = central_waves_per_block();
@@ -562,7 +623,7 @@ class SolverImpl final : public SolverBase {
         const int groups = (d.N + agents_per_block - 1) / agents_per_block;
         // up to 32 working workgroups (one per CU of an XCD) are placed on ONE XCD by launching eight times as many and letting
         // every eighth work (LadderSync::xcd_stride); only the pipelined kernel knows the stride
-        sy.xcd_stride = (central_pipelined() && groups > 1 && groups <= 32 && central_one_xcd()) ? 8 : 1;
+        sy.xcd_stride = (central_pipelined() && groups > 1 && groups <= 32 && central_one_xcd() && ladder_one_xcd_ok) ? 8 : 1;
         be.launch_kernel(kernel, dim3(groups * sy.xcd_stride), dim3(64 * w), d, P, X, D, kff, Kfb,
                          reg_events, active, 0, static_cast<int>(d.N), sy);
       };
@@ -620,7 +681,7 @@ class SolverImpl final : public SolverBase {
   // the backward kernel with the shared ladder, W wavefronts per workgroup: the registers + DPP form for NX == 4, else the LDS-tile form
   using BackwardKernelFn = void (*)(Dims, ModelParams, const double*, const double*, double*, double*, long long*, const int*, int, int, LadderSync);
   template <int W>
-  static BackwardKernelFn central_kernel() {
+  BackwardKernelFn central_kernel() const {
     if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) {
       if (!backward_tile_forced()) {
         if (!central_pipelined()) return mas_backward_row_kernel<M, true, W>;
@@ -629,15 +690,14 @@ class SolverImpl final : public SolverBase {
     }
     return mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, W>;
   }
-  static bool central_pipelined() {                                    // A/B: MAS_HIP_CENTRAL_PIPELINE=0 = the plain registers + DPP kernel with the shared ladder
+  bool central_pipelined() const {                                     // false = the plain registers + DPP kernel with the shared ladder
     if constexpr (!(NX == 4 && kBackwardLanesPerAgent == 16)) return false;
-    if (backward_tile_forced()) return false;
-    const char* e = std::getenv("MAS_HIP_CENTRAL_PIPELINE");
-    return !(e && e[0] == '0');
+    return !backward_tile_forced() && switches.central_pipeline;
   }
-  static bool backward_list_enabled() { const char* e = std::getenv("MAS_HIP_BACKWARD_LIST"); return !(e && e[0] == '0'); }   // A/B: 0 = the LDS-tile kernel walks all agents by their flags
-  static bool central_one_xcd() { const char* e = std::getenv("MAS_HIP_CENTRAL_ONE_XCD"); return !(e && e[0] == '0'); }
-  static bool backward_tile_forced() { const char* e = std::getenv("MAS_HIP_BACKWARD_TILE"); return e && e[0] == '1'; }   // A/B: the LDS-tile kernel also for NX == 4
+  bool backward_list_enabled() const { return switches.backward_list; }
+  bool central_one_xcd() const { return switches.central_one_xcd; }
+  bool backward_tile_forced() const { return switches.backward_tile; }
+  void on_option_changed() override { ladder_resident_checked = false; }
   // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
   // them resident at once.  Checked against the occupancy the runtime reports for this kernel on this device (a
   // partitioned device, e.g. CPX with 32 CUs, or a build with higher register use may not hold them); if they do not fit,
@@ -645,8 +705,7 @@ class SolverImpl final : public SolverBase {
   // processes on the device is outside what can be checked here: mas_hip.h states the exclusivity requirement.
   // wavefronts per workgroup of the centralised backward pass (see mas_backward_tile_kernel): measured on C2
   int central_waves_per_block() const {
-    if (const char* e = std::getenv("MAS_HIP_CENTRAL_WPB")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return v; }
-    return kCentralWavesPerBlock;
+    return switches.central_wpb;
   }
   bool ladder_resident() {
     if (ladder_resident_checked) return ladder_resident_ok;
@@ -663,10 +722,12 @@ class SolverImpl final : public SolverBase {
     else q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<1>(), 64, 0);
     if (q != hipSuccess || hipGetDeviceProperties(&prop, be.device) != hipSuccess) { (void)hipGetLastError(); ladder_resident_ok = false; return false; }
     ladder_resident_ok = static_cast<long long>(per_cu) * prop.multiProcessorCount >= grid;
-    if (const char* f = std::getenv("MAS_HIP_FORCE_SINGLE_WORKGROUP_CENTRAL")) { if (f[0] == '1') ladder_resident_ok = false; }   // tests: exercise the fallback
+    // the one-XCD placement puts all working workgroups on an eighth of the CUs: it needs them resident THERE
+    ladder_one_xcd_ok = static_cast<long long>(per_cu) * (prop.multiProcessorCount / 8) >= grid;
+    if (switches.force_single_workgroup_central) ladder_resident_ok = false;   // tests: exercise the fallback
     return ladder_resident_ok;
   }
-  bool ladder_resident_checked = false, ladder_resident_ok = false;
+  bool ladder_resident_checked = false, ladder_resident_ok = false, ladder_one_xcd_ok = false;
 #endif
 
   ALView al_view(bool on) const {
@@ -723,7 +784,7 @@ class SolverImpl final : public SolverBase {
     if (debug && !dbg_iter) { dbg_iter = ialloc(d.Np); dbg_improvement = dalloc(d.Np); }
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
                                                            counters, 2 * kCounterRing, live_lists[0], live_count0, d.N,
-                                                           solves_left, n_solves - 1, timed ? solve_start : nullptr}, d.N);
+                                                           solves_left, n_solves - 1, timed ? solve_start : nullptr, slot_of[0]}, d.N);
     if (!rollout_consistent) {
       launch_rollout_cost();
       rollout_consistent = true;
@@ -733,6 +794,11 @@ class SolverImpl final : public SolverBase {
     if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
     if (debug) debug_initial();
     const ForwardBody<M> fwd = make_forward();
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (kFusable) {
+      if (fused_enabled() && !trust_epilogue && !debug) { fused_rounds(n_solves, timed, fwd); return; }
+    }
+#endif
 #if defined(MAS_HOST_EMULATION)
     const bool run_ahead = false;
 #else
@@ -817,6 +883,81 @@ class SolverImpl final : public SolverBase {
     last_solve_rounds = rounds_this_solve;
   }
 
+#if !defined(MAS_HOST_EMULATION)
+  // ---- fused rounds (mas_fused_hip.hpp): round = [select of the round before + commit + linearisation || Riccati] -> line search ----
+  // helpers / ring: finite-difference models need four helper wavefronts to stay ahead of the recursion, analytic ones two
+  static constexpr int kFusedHelpers = (M::kAnalyticA && M::kAnalyticLxx) ? 2 : 4, kFusedRing = 2;
+  bool fused_enabled() const { return switches.fused; }
+  double fused_bytes() const { return sweep_bytes() + backward_bytes(); }
+  void launch_fused(const FusedRound& fr, double bytes) {
+    using FL = FusedLayout<M, kFusedHelpers, kFusedRing>;
+    be.begin("linearise_riccati", bytes);
+    be.launch_kernel_lds(mas_linearise_riccati_kernel<M, kFusedHelpers, kFusedRing>, dim3(static_cast<unsigned>((d.N + kFusedAgents - 1) / kFusedAgents)),
+                         dim3(FL::kThreads), FL::kBytes, d, P, X, U, kff, Kfb, reg_events, fr);
+    be.end();
+  }
+  // Round r:  fused(r) runs select(r-1) (r > 0), commits what it accepted, linearises and walks the recursion for the agents
+  // still active; forward(r) rolls out their trials and its first lane publishes the counters of select(r-1).  So the host
+  // learns the outcome of round r-1 with the event of round r -- one round later than the unfused loop -- and the loop ends
+  // with the round whose select found no active agent left (that round's commit has run in the same kernel).
+  void fused_rounds(int n_solves, bool timed, const ForwardBody<M>& fwd_proto) {
+    const long long round_limit = static_cast<long long>(max_iterations) * n_solves;   // the last select runs in round `round_limit`
+    constexpr int kRing = kCounterRing;
+    struct Marks { size_t p0, p1; };
+    Marks marks[2];
+    bool by_slot[2] = {false, false};
+    be.zero(fused_error, sizeof(int));
+    auto enqueue = [&](long long r) {
+      Marks& mk = marks[r & 1];
+      mk.p0 = be.mark();
+      FusedRound fr;
+      long long* ctr_prev = counters + 2 * ((r + kRing - 1) % kRing);            // counted by select(r-1), which runs in this round's first kernel
+      long long* ctr_clear = counters + 2 * ((r + 1) % kRing);
+      fr.sel = SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
+                          iters_total, exit_code, reinterpret_cast<int*>(ctr_prev), ctr_prev + 1, ctr_clear,
+                          nullptr, nullptr, live_lists[r & 1], n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
+                          nullptr, nullptr, nullptr, slot_of[r & 1]};
+      fr.do_select = r > 0 ? 1 : 0;
+      fr.Xs = Xs; fr.Us = Us; fr.planes_by_slot = by_slot[(r + 1) & 1] ? 1 : 0; fr.slot_prev = slot_of[(r + 1) & 1];
+      fr.error = fused_error;
+      launch_fused(fr, fused_bytes());
+      ForwardBody<M> fwd = fwd_proto;
+      if (r > 0) fwd.publish = Publish{ctr_prev, host_counters + 16 + 4 * ((r + kRing - 1) % kRing), 2, fused_error};     // pinned words 16..31: {active, converged, error flag, -} per ring slot
+      const int* live = (r == 0) ? live_count0 : reinterpret_cast<const int*>(ctr_prev);
+      by_slot[r & 1] = launch_forward(fwd, forward_bytes() * kNumAlphas, live_lists[r & 1], live, live_upper);
+      be.record(round_ev[r & 1]);
+      mk.p1 = be.mark();
+    };
+    long long n_before = d.N;             // agents active at the start of the round whose outcome is read next
+    live_upper = d.N;
+    long long enq = 0; int rounds_this_solve = 0; bool gave_up = false;
+    if (max_iterations > 0 && !(timed && 0.0 > max_ms)) { enqueue(0); enq = 1; }
+    else if (max_iterations > 0) be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
+    for (long long r = 0; r < enq; ++r) {
+      if (enq == r + 1 && r + 1 <= round_limit) { enqueue(r + 1); ++enq; }       // the host runs one round ahead of the device
+      be.wait(round_ev[r & 1]);
+      // the line search of round r ran on the agents active at its start: N in round 0, else what select(r-1) left
+      if (r == 0) { be.scale_bytes(marks[0].p0, marks[0].p1, static_cast<double>(d.N)); continue; }
+      const long long* hc = host_counters + 16 + 4 * ((r + kRing - 1) % kRing);
+      const long long n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]);
+      if (hc[2] != 0) { gave_up = true; break; }
+      stats.agent_iterations += n_before;
+      stats.converged_solves += hc[1];
+      stats.batch_iterations++; ++rounds_this_solve;
+      be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_after));
+      n_before = n_after;
+      live_upper = std::max<long long>(n_after, 1);
+      if (n_after == 0) {
+        if (enq > r + 1) be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0);
+        break;
+      }
+    }
+    if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);   // drain a round that ran ahead
+    last_solve_rounds = rounds_this_solve;
+    if (gave_up) throw std::runtime_error("fused round: a bounded wait inside a workgroup gave up");
+  }
+#endif
+
   // "debug" key (ilqr.hpp:45,79-80,262-267): the reference prints one line per solve start and one per iteration of
   // every agent (interleaved arbitrarily across OpenMP threads); here the same lines, agent by agent after each round,
   // prefixed with the agent's position in the batch
@@ -874,6 +1015,7 @@ class SolverImpl final : public SolverBase {
   double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
+  int *slot_of[2] = {nullptr, nullptr}, *fused_error = nullptr;   // fused rounds: every agent's position in live_lists[k]; raised when a bounded LDS wait gave up
   int *live_lists[2] = {nullptr, nullptr}, *live_count0 = nullptr;   // agents still active, compacted by select (round r reads list r & 1, writes the other); count of round 0 (= N)
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
   int *trust_verdict = nullptr, *trust_ended = nullptr, *trust_roll_list = nullptr, *trust_roll_count = nullptr;   // chained trust-region epilogue

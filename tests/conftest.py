@@ -41,9 +41,12 @@ def product_lib():
     return _capi.load(g.build_hip())
 
 
-def run_batch(lib, model, x0, U0, T, dt, strategy, max_outer=10, max_iterations=100, tolerance=1e-5, max_ms=math.inf, **kw):
+def run_batch(lib, model, x0, U0, T, dt, strategy, max_outer=10, max_iterations=100, tolerance=1e-5, max_ms=math.inf, options=None, **kw):
+    """options: kernel forms (mas_hip_set_option) -- bit-identical alternatives of the same launches"""
     from multi_agent_solver_amd.batch import BatchSolver
     with BatchSolver(model, x0.shape[0], T, dt, lib=lib, **kw) as s:
+        for key, value in (options or {}).items():
+            s.set_option(key, value)
         s.set_params({"max_iterations": max_iterations, "tolerance": tolerance, "max_ms": max_ms})
         s.set_initial_states(x0)
         s.set_controls(U0)

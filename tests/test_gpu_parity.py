@@ -48,13 +48,17 @@ def test_single_track_h100(gpu_lib, oracle, strategy):
     _same(e, o, total_exact=(strategy != "centralized"))
 
 
-def test_staged_sweep_and_backward(gpu_lib, oracle):
+@pytest.mark.parametrize("fused", [1, 0])
+def test_staged_sweep_and_backward(gpu_lib, oracle, fused):
+    """derivative tiles, gains and rollout of ONE linearisation + backward pass against the oracle, element by element: through the
+    fused linearise + Riccati kernel (its tiles dumped from the LDS ring) and through the separate sweep and backward kernels"""
     from multi_agent_solver_amd.batch import BatchSolver
     N, T = 70, 30
     x0 = oracle.single_track_x0(N)
     rng = np.random.default_rng(1)
     U = 0.3 * rng.standard_normal((N, T, 2))
     with BatchSolver(oracle.MODEL_SINGLE_TRACK, N, T, 0.5, lib=gpu_lib) as s:
+        s.set_option("fused", fused)
         s.set_initial_states(x0)
         s.set_controls(U)
         s.initialize_problem()
@@ -344,13 +348,12 @@ def test_handle_on_the_callers_stream(gpu_lib, oracle):
     assert abs(total - o["cost"].sum()) <= 1e-9 * o["cost"].sum()
 
 
-def test_centralized_single_workgroup_fallback(gpu_lib, oracle, monkeypatch):
+def test_centralized_single_workgroup_fallback(gpu_lib, oracle):
     """when the workgroups of the rung-agreement kernel cannot all be resident (occupancy check), the
     centralised backward pass falls back to the single-workgroup kernel -- same results, bit for bit."""
     x0 = oracle.single_track_x0(70)
     fast = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 40, 0.5, "centralized")
-    monkeypatch.setenv("MAS_HIP_FORCE_SINGLE_WORKGROUP_CENTRAL", "1")
-    slow = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 40, 0.5, "centralized")
+    slow = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 40, 0.5, "centralized", options={"force_single_workgroup_central": 1})
     for key in ("cost", "X", "U", "iters"):
         assert np.array_equal(fast[key], slow[key]), key
     assert fast["stats"]["reg_events"] == slow["stats"]["reg_events"] and fast["total_cost"] == slow["total_cost"]
@@ -428,31 +431,57 @@ def test_division_by_an_invariant_divisor_is_the_ieee_quotient():
 @pytest.mark.parametrize("model,T,dt,strategy,outer", [("MODEL_SINGLE_TRACK", 60, 0.5, "sequential", 4), ("MODEL_SINGLE_TRACK", 40, 0.5, "trustregion", 3),
                                                        ("MODEL_SINGLE_TRACK", 40, 0.5, "centralized", 1), ("MODEL_LQR_IDENTITY", 30, 0.1, "sequential", 3),
                                                        ("MODEL_SINGLE_TRACK_LANE", 50, 0.1, "sequential", 2), ("MODEL_BICYCLE6", 80, 0.25, "trustregion", 3)])
-def test_kernel_forms_agree(gpu_lib, oracle, monkeypatch, model, T, dt, strategy, outer):
+def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
     """The second half of round 2 added a second form of three kernels: line search / initial rollout / trust-region re-roll with
     four lanes per rollout (DPP quads) beside one lane per rollout, and the backward pass in registers + DPP (NX = 4) beside the
     LDS-tile form.  Which form runs depends on the number of live agents and the model; here the same perturbed problem is
     solved with the new forms (default: 330 agents are below the four-lane bound from round 0 on) and with the round-1 forms
-    forced by the library's A/B switches -- equal results (and both equal to the oracle)."""
+    forced through mas_hip_set_option -- equal results (and both equal to the oracle).  Round 3: the default is also the two-kernel
+    fused round (mas_fused_hip.hpp) for the four-state models; "fused": 0 gives the five-kernel round with the new forms."""
     mid = getattr(oracle, model)
     N = 330
     rng = np.random.default_rng(7)
     base = {"MODEL_LQR_IDENTITY": lambda: oracle.lqr_x0(N), "MODEL_BICYCLE6": lambda: oracle.bicycle6_x0(N)}.get(model, lambda: oracle.single_track_x0(N))()
     x0 = base + 0.05 * rng.standard_normal(base.shape)
     new = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer)
-    monkeypatch.setenv("MAS_HIP_FORWARD_QUAD_MAX", "0")
-    monkeypatch.setenv("MAS_HIP_BACKWARD_TILE", "1")
-    old = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer)
-    for key in ("cost", "X", "U", "iters", "status"):
-        assert np.array_equal(new[key], old[key]), key
-    assert new["stats"]["reg_events"] == old["stats"]["reg_events"]
+    old = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"fused": 0, "forward_quad_max": 0, "backward_tile": 1})
+    unfused = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"fused": 0})
+    fused_one_lane = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"forward_quad_max": 0})
+    for other in (old, unfused, fused_one_lane):
+        for key in ("cost", "X", "U", "iters", "status"):
+            assert np.array_equal(new[key], other[key]), key
+        assert new["stats"]["reg_events"] == other["stats"]["reg_events"]
+        assert new["stats"]["agent_iterations"] == other["stats"]["agent_iterations"] and new["stats"]["converged_solves"] == other["stats"]["converged_solves"]
     o = oracle.solve_batch(mid, x0, None, T, dt, strategy=strategy, max_outer=outer)
     _same(new, o, total_exact=(strategy != "centralized"))
 
 
+@pytest.mark.parametrize("model,N,T,dt,outer", [("MODEL_SINGLE_TRACK", 2100, 41, 0.5, 3), ("MODEL_SINGLE_TRACK", 1, 7, 0.5, 2), ("MODEL_SINGLE_TRACK", 17, 3, 0.5, 2),
+                                                ("MODEL_LQR_IDENTITY", 1700, 50, 0.1, 3), ("MODEL_SINGLE_TRACK_LANE", 1650, 30, 0.1, 2)])
+def test_fused_round_agrees_across_the_line_search_forms(gpu_lib, oracle, model, N, T, dt, outer):
+    """Two-kernel fused rounds (mas_fused_hip.hpp) on batches that start above the four-lane bound of the line search (trial
+    planes indexed by agent) and fall below it as agents retire (planes indexed by slot): the commit inside the fused kernel
+    has to find each agent's accepted trial in either layout.  Horizons that are not multiples of the helpers' four-step
+    chunks, a single agent, a workgroup with one agent.  Against the five-kernel round and, on a sample, the oracle."""
+    mid = getattr(oracle, model)
+    rng = np.random.default_rng(5)
+    base = oracle.lqr_x0(N) if model == "MODEL_LQR_IDENTITY" else oracle.single_track_x0(N)
+    x0 = base + 0.05 * rng.standard_normal(base.shape)
+    new = run_batch(gpu_lib, mid, x0, None, T, dt, "sequential", max_outer=outer)
+    old = run_batch(gpu_lib, mid, x0, None, T, dt, "sequential", max_outer=outer, options={"fused": 0})
+    for key in ("cost", "X", "U", "iters", "status"):
+        assert np.array_equal(new[key], old[key]), key
+    for key in ("reg_events", "agent_iterations", "converged_solves", "solves"):
+        assert new["stats"][key] == old["stats"][key], key
+    sample = np.arange(0, N, max(1, N // 60))
+    o = oracle.solve_batch(mid, x0[sample], None, T, dt, strategy="sequential", max_outer=outer)
+    assert np.array_equal(new["cost"][sample], o["cost"]) and np.array_equal(new["X"][sample], o["X"]) and np.array_equal(new["U"][sample], o["U"])
+    assert new["iters"][sample].tolist() == o["iters"].tolist()
+
+
 @pytest.mark.parametrize("model,N,T", [("MODEL_SINGLE_TRACK", 10, 30), ("MODEL_SINGLE_TRACK", 70, 40), ("MODEL_SINGLE_TRACK", 600, 25),
                                        ("MODEL_LQR_IDENTITY", 40, 20), ("MODEL_SINGLE_TRACK_LANE", 90, 30)])
-def test_centralized_speculative_pass_agrees(gpu_lib, oracle, monkeypatch, model, N, T):
+def test_centralized_speculative_pass_agrees(gpu_lib, oracle, model, N, T):
     """The centralised backward pass hides the rung agreement behind a speculative step (mas_backward_row_pipelined_kernel): one
     workgroup (N = 10), several on one XCD (70, 40, 90), more than an XCD holds (600); NU = 2 and NU = 4; perturbed agents, so that
     the agreed rung often differs from the one a wavefront assumed and steps are redone.  Same results as the plain kernel with
@@ -463,10 +492,8 @@ def test_centralized_speculative_pass_agrees(gpu_lib, oracle, monkeypatch, model
     x0 = base + 0.05 * rng.standard_normal(base.shape)
     dt = 0.1 if model != "MODEL_SINGLE_TRACK" else 0.5
     new = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
-    monkeypatch.setenv("MAS_HIP_CENTRAL_PIPELINE", "0")
-    plain = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
-    monkeypatch.setenv("MAS_HIP_BACKWARD_TILE", "1")
-    tile = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
+    plain = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, options={"central_pipeline": 0})
+    tile = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, options={"central_pipeline": 0, "backward_tile": 1})
     for other in (plain, tile):
         for key in ("cost", "X", "U", "iters"):
             assert np.array_equal(new[key], other[key]), key
