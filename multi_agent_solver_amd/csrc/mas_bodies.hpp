@@ -190,7 +190,16 @@ struct BackwardBody {
 struct Publish {
   const long long* src = nullptr; long long* host = nullptr; int words = 0;
   const int* flag = nullptr;        // optional: one more word, host[words] = *flag (the centralised pass's "gave up waiting" flag)
+  // tag != 0 (fused rounds, which the host POLLS for instead of waiting on an event): the counter pair {int active, long long
+  // converged}, the flag and the tag travel as ONE 64-bit store -- [tag:15][flag:1][converged:24][active:24] -- so the host can
+  // never see a tag without its counters
+  int tag = 0;
+  static constexpr int kTagShift = 49, kFlagShift = 48, kConvShift = 24; static constexpr long long kMask24 = 0xFFFFFF;
+  MAS_HD static long long pack(int tag_, int flag_, long long conv, long long act) {
+    return (static_cast<long long>(tag_ & 0x7FFF) << kTagShift) | (static_cast<long long>(flag_ != 0) << kFlagShift) | ((conv & kMask24) << kConvShift) | (act & kMask24);
+  }
   MAS_HD void operator()() const {
+    if (tag != 0) { *reinterpret_cast<volatile long long*>(host) = pack(tag, flag ? *flag : 0, src[1], src[0] & 0xFFFFFFFFll); return; }
     for (int i = 0; i < words; ++i) host[i] = src[i];
     if (flag) host[words] = static_cast<long long>(*flag);
   }

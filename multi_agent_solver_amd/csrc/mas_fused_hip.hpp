@@ -155,10 +155,6 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
   fetch(tA, d.T - 1);
   auto step = [&](int t, const Tile& c, Tile& nx) {
     MAS_UNROLL for (int m = 0; m < NU; ++m) { MAS_OPAQUE32(goff[m]); MAS_OPAQUE32(koff[m]); }
-    if (t > 0) {
-      if (((t - 1) & 3) == 3) acquire(t - 1);                          // uniform: the next tile opens a new chunk
-      fetch(nx, t - 1);
-    }
     const double* Ai = c.Ai; const double* Aj = c.Aj; const double* Bi = c.Bi; const double* Bj = c.Bj;
 
     // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
@@ -179,13 +175,17 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
       qu_own = c.lu + s;
     }
     wave_sync();
-    // the tile requested above has arrived with this wait: if it was the last of its chunk, the helpers may reuse the slot
-    if (t > 0 && ((t - 1) & 3) == 0 && tid == 0) ctl->consumed[wave] = C - ((t - 1) >> 2);
     // ---- pass 2 (second factors of ilqr.hpp:117-119)
     double quu[NU * NU], qu[NU], quxj[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU], qxx_own;
     {
       double ra[NX], rb[NX];
       MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
+      // the next step's tile is requested HERE, behind the operand reads of pass 2 (an LDS queue serves one wavefront's
+      // instructions in order): its ~20 reads travel in the shadow of passes 2 and 3 instead of in front of the wait above
+      if (t > 0) {
+        if (((t - 1) & 3) == 3) acquire(t - 1);                        // uniform: the next tile opens a new chunk
+        fetch(nx, t - 1);
+      }
       double s;
       s = sum_terms<NX>([&](int k) { return ra[k] * Aj[k]; });
       qxx_own = c.lxx + s;
@@ -313,6 +313,9 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
         MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[m], Ki[m]);
       }
     }
+    // the tile requested in pass 2 has arrived (pass 3 waited for every LDS operation): if it was the last of its chunk, the
+    // helpers may reuse the slot
+    if (t > 0 && ((t - 1) & 3) == 0 && tid == 0) ctl->consumed[wave] = C - ((t - 1) >> 2);
     kff_t -= static_cast<size_t>(NU) * d.Np; Kfb_t -= static_cast<size_t>(NU) * NX * d.Np;
   };
   int t = d.T - 1;
@@ -382,14 +385,11 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
   const int a_base = static_cast<int>(blockIdx.x) * kFusedAgents;
 
   // ---- phase 0: the previous round's select for this workgroup's agents (wavefront 0, lanes 0..15)
+  int sel_outcome = SelectBody::kIdle;
   if (wave == 0) {
     const int a = a_base + lane;
     const bool mine = lane < kFusedAgents && a < d.N;
-    if (fr.do_select) {                                                 // uniform
-      int r = SelectBody::kIdle;
-      if (mine) r = fr.sel.decide(a);
-      fr.sel.count(r, a);
-    }
+    if (fr.do_select && mine) sel_outcome = fr.sel.decide(a);
     int act = 0, jsel = -1;
     if (mine) { act = fr.sel.active[a]; jsel = fr.sel.alpha_sel[a]; }
     if (lane < kFusedAgents) {
@@ -401,6 +401,9 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
     if (lane < 4) { ctl->ready[lane] = 0; ctl->consumed[lane] = 0; }
   }
   __syncthreads();
+  // counters and the next round's live list (two atomics, one of them returning) AFTER the barrier: the helpers are on their
+  // first chunk by now, and this wavefront's recursion cannot start before that chunk is there
+  if (wave == 0 && fr.do_select) fr.sel.count(sel_outcome, a_base + lane);
   const bool any_act = ctl->any_act != 0, any_pend = ctl->any_pend != 0;
   if (!any_act && !any_pend) return;
 
@@ -411,7 +414,9 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
       if (lane == 0) ctl->consumed[wave] = 0x7fffffff;
       return;
     }
+#if !defined(MAS_FUSED_NO_PRIO)
     __builtin_amdgcn_s_setprio(3);                                     // the chain goes first; the helpers fill the issue slots it leaves
+#endif
     const int jsel = ctl->selj[al0];
     const double* xT_src = (jsel >= 0) ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * M::NX * d.Np : X;
     fused_backward_wave<M, HELPERS, RING>(d, P, lds, ctl, wave, a_base, xT_src, static_cast<unsigned>(ctl->col[al0]), kff, Kfb, reg_events, fr.error);

@@ -143,7 +143,9 @@ template <class M>
 class SolverImpl final : public SolverBase {
   static constexpr int NX = M::NX, NU = M::NU;
   static constexpr bool kConstrained = (M::NEQ + M::NIN) > 0;
-  static constexpr bool kFusable = NX == 4 && !kConstrained;     // the two-kernel round of mas_fused_hip.hpp
+  // the two-kernel round of mas_fused_hip.hpp; NU <= 2: with NU = 4 the recursion alone fills the 256 VGPRs a wavefront may have
+  // when helper wavefronts share its SIMD (measured: 54 spilled registers, C4 17.3 -> 21.5 ms)
+  static constexpr bool kFusable = NX == 4 && NU <= 2 && !kConstrained;
   using L = DerivLayout<M>;
 
  public:
@@ -886,7 +888,11 @@ class SolverImpl final : public SolverBase {
 #if !defined(MAS_HOST_EMULATION)
   // ---- fused rounds (mas_fused_hip.hpp): round = [select of the round before + commit + linearisation || Riccati] -> line search ----
   // helpers / ring: finite-difference models need four helper wavefronts to stay ahead of the recursion, analytic ones two
+#if defined(MAS_FUSED_HELPERS)
+  static constexpr int kFusedHelpers = MAS_FUSED_HELPERS, kFusedRing = MAS_FUSED_RING;      // (A/B builds)
+#else
   static constexpr int kFusedHelpers = (M::kAnalyticA && M::kAnalyticLxx) ? 2 : 4, kFusedRing = 2;
+#endif
   bool fused_enabled() const { return switches.fused; }
   double fused_bytes() const { return sweep_bytes() + backward_bytes(); }
   void launch_fused(const FusedRound& fr, double bytes) {
@@ -907,6 +913,8 @@ class SolverImpl final : public SolverBase {
     Marks marks[2];
     bool by_slot[2] = {false, false};
     be.zero(fused_error, sizeof(int));
+    volatile long long* words = host_counters + 16;                     // pinned words 16 .. 16 + kRing - 1: one packed word per round (Publish::pack)
+    for (int q = 0; q < kRing; ++q) words[q] = 0;                       // (the device writes nothing here before round 1 of this call)
     auto enqueue = [&](long long r) {
       Marks& mk = marks[r & 1];
       mk.p0 = be.mark();
@@ -922,39 +930,50 @@ class SolverImpl final : public SolverBase {
       fr.error = fused_error;
       launch_fused(fr, fused_bytes());
       ForwardBody<M> fwd = fwd_proto;
-      if (r > 0) fwd.publish = Publish{ctr_prev, host_counters + 16 + 4 * ((r + kRing - 1) % kRing), 2, fused_error};     // pinned words 16..31: {active, converged, error flag, -} per ring slot
+      if (r > 0) { fwd.publish = Publish{ctr_prev, host_counters + 16 + (r % kRing), 2, fused_error}; fwd.publish.tag = static_cast<int>((r + 1) & 0x7FFF); }
       const int* live = (r == 0) ? live_count0 : reinterpret_cast<const int*>(ctr_prev);
       by_slot[r & 1] = launch_forward(fwd, forward_bytes() * kNumAlphas, live_lists[r & 1], live, live_upper);
-      be.record(round_ev[r & 1]);
       mk.p1 = be.mark();
+    };
+    // The first lane of forward(r) publishes the outcome of select(r-1) in ONE 64-bit store to pinned memory and the host polls
+    // that word: no event between the kernels of consecutive rounds (an event record costs ~6 us of gap per round), and the host
+    // knows a whole line search ahead whether round r+1 is needed -- it is, exactly when round r still had active agents -- so
+    // nothing is enqueued speculatively and the loop ends with the round that only selects and commits.
+    auto await = [&](long long r) -> long long {
+      const long long want = (r + 1) & 0x7FFF;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (long long spins = 1;; ++spins) {
+        const long long w = words[r % kRing];
+        if (((w >> Publish::kTagShift) & 0x7FFF) == want) return w;
+        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+          throw std::runtime_error("fused round: the device did not publish a round's counters within 30 s");
+      }
     };
     long long n_before = d.N;             // agents active at the start of the round whose outcome is read next
     live_upper = d.N;
-    long long enq = 0; int rounds_this_solve = 0; bool gave_up = false;
-    if (max_iterations > 0 && !(timed && 0.0 > max_ms)) { enqueue(0); enq = 1; }
-    else if (max_iterations > 0) be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
-    for (long long r = 0; r < enq; ++r) {
-      if (enq == r + 1 && r + 1 <= round_limit) { enqueue(r + 1); ++enq; }       // the host runs one round ahead of the device
-      be.wait(round_ev[r & 1]);
-      // the line search of round r ran on the agents active at its start: N in round 0, else what select(r-1) left
-      if (r == 0) { be.scale_bytes(marks[0].p0, marks[0].p1, static_cast<double>(d.N)); continue; }
-      const long long* hc = host_counters + 16 + 4 * ((r + kRing - 1) % kRing);
-      const long long n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]);
-      if (hc[2] != 0) { gave_up = true; break; }
-      stats.agent_iterations += n_before;
-      stats.converged_solves += hc[1];
-      stats.batch_iterations++; ++rounds_this_solve;
-      be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_after));
-      n_before = n_after;
-      live_upper = std::max<long long>(n_after, 1);
-      if (n_after == 0) {
-        if (enq > r + 1) be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0);
-        break;
+    int rounds_this_solve = 0; bool gave_up = false;
+    if (max_iterations > 0 && !(timed && 0.0 > max_ms)) {
+      enqueue(0);
+      enqueue(1);                         // select(0) + commit: always needed
+      be.scale_bytes(marks[0].p0, marks[0].p1, static_cast<double>(d.N));
+      for (long long r = 1;; ++r) {       // rounds 0 .. r are enqueued
+        const long long w = await(r);
+        const long long n_after = w & Publish::kMask24, conv = (w >> Publish::kConvShift) & Publish::kMask24;
+        if ((w >> Publish::kFlagShift) & 1) { gave_up = true; break; }
+        stats.agent_iterations += n_before;           // round r-1 ran one iLQR iteration on every agent active at its start
+        stats.converged_solves += conv;
+        stats.batch_iterations++; ++rounds_this_solve;
+        be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_after));
+        n_before = n_after;
+        live_upper = std::max<long long>(n_after, 1);
+        if (n_after == 0 || r + 1 > round_limit) break;
+        enqueue(r + 1);
       }
+    } else if (max_iterations > 0) {
+      be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
     }
-    if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);   // drain a round that ran ahead
     last_solve_rounds = rounds_this_solve;
-    if (gave_up) throw std::runtime_error("fused round: a bounded wait inside a workgroup gave up");
+    if (gave_up) { be.sync(); throw std::runtime_error("fused round: a bounded wait inside a workgroup gave up"); }
   }
 #endif
 
