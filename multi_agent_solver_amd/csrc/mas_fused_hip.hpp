@@ -57,6 +57,7 @@ struct FusedLayout {
   static constexpr int oBwd = 0, oRing = oBwd + kFusedAgents * kBwdStride, oCtl = oRing + RING * 64 * TS;
   static constexpr size_t kBytes = sizeof(double) * oCtl + sizeof(FusedCtl);
   static constexpr int kThreads = 64 * (4 + HELPERS);
+  static_assert(RING > 0 ? HELPERS >= 1 : HELPERS <= 1, "RING == 0: no linearising helpers (at most the one wavefront that commits)");
 };
 
 // one LDS word, re-read until `done(value)`; uniform over the wavefront
@@ -73,14 +74,112 @@ __device__ __forceinline__ bool lds_wait(const volatile int* word, Pred done, in
   }
 }
 
-// ---- the recursion of one backward wavefront (4 agents, 16 lanes each): mas_backward_row_kernel's step, operands from the LDS ring --
+// this lane's operands of one time step of the recursion (mas_backward_row_kernel): two columns of A and B and five scalars
+struct RowTile { double Ai[4], Aj[4], Bi[4], Bj[4]; double lx, lu, lxx, lux, luu; };
+__device__ __forceinline__ double pick4(int idx, double a0, double a1, double a2, double a3) {
+  double r = a0; r = (idx == 1) ? a1 : r; r = (idx == 2) ? a2 : r; r = (idx == 3) ? a3 : r; return r;
+}
+
+// Where the recursion's tiles come from.  A source provides
+//   Raw                      what travels one step ahead of its use
+//   begin()                  before the first request
+//   request(raw, t)          ask for the operands of step t (t >= 0); kRequestLate: issued behind the operand reads of pass 2
+//   make(raw, t, tile)       at the start of step t: this lane's RowTile
+//   arrived(t)               every LDS operation of the step that requested step t's operands has completed
+// ---- tiles produced by the helper wavefronts, in the LDS ring
 template <class M, int HELPERS, int RING>
-__device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelParams& P, double* __restrict__ lds, FusedCtl* ctl,
-                                                    int wave, int a_base, const double* __restrict__ xT_src, unsigned xT_col,
-                                                    double* __restrict__ kff, double* __restrict__ Kfb, long long* __restrict__ reg_events, int* error) {
+struct RingSource {
   using FL = FusedLayout<M, HELPERS, RING>;
   using L = DerivLayout<M>;
-  constexpr int NX = 4, NU = M::NU, TS = FL::TS;
+  static constexpr int NX = 4, NU = M::NU, TS = FL::TS;
+  static constexpr bool kMerged = NU <= 2, kRequestLate = true;
+  using Raw = RowTile;
+  const double* ring; FusedCtl* ctl; int* error; int wave, al, C, tid;
+  int eAi, eAj, eBi, eBj, elx, elu, elxx, elux, eluu;
+  __device__ RingSource(double* lds, FusedCtl* ctl_, int* error_, int wave_, int al_, int T, int lane, int i, int j, int iu, int ju)
+      : ring(lds + FL::oRing), ctl(ctl_), error(error_), wave(wave_), al(al_), C((T + 3) >> 2), tid(static_cast<int>(threadIdx.x) & 63) {
+    // element indices of this lane's operands (the ring holds plain tiles, TS doubles apart)
+    eAi = L::oA + 4 * i; eAj = L::oA + 4 * j; eBi = L::oB + 4 * iu; eBj = L::oB + 4 * ju;
+    elx = L::oLx + i; elu = L::oLu + iu; elxx = L::oLxx + lane; elux = L::oLux + iu + NU * j; eluu = L::oLuu + iu + NU * ju;
+    if constexpr (kMerged) {                                           // merged second round of pass 2, see mas_backward_row_kernel
+      const int item2 = (i < NU) ? 0 : ((i >= 2 && j < NU && i - 2 < NU) ? 1 : ((i >= 2 && j >= 2) ? 2 : 3));
+      const int c2 = (i - 2) + 2 * (j - 2);
+      if (item2 == 0) { eBj = eAj; }
+      else if (item2 == 1) { eBj = L::oB + 4 * j; elux = L::oLuu + (i - 2) + NU * j; }
+      else if (item2 == 2) { eBj = L::oA + 4 * c2; elux = L::oLx + c2; }
+      else { eBj = eAj; }
+    }
+  }
+  // tile of step t: chunk n = C-1 - t/4 (the order the helpers produce them in), ring slot n % RING, tile (t & 3) * 16 + agent
+  __device__ __forceinline__ void acquire(int t) const {
+    const int n = C - 1 - (t >> 2);
+    lds_wait(&ctl->ready[n % RING], [n](int v) { return v >= n + 1; }, error);
+  }
+  __device__ __forceinline__ void begin() const {}
+  __device__ __forceinline__ void request(Raw& o, int t, bool first) const {
+    if (first || (t & 3) == 3) acquire(t);                             // uniform: this tile opens a new chunk
+    const int n = C - 1 - (t >> 2);
+    const double* tile = ring + (static_cast<size_t>(n % RING) * 64 + static_cast<size_t>(t & 3) * 16 + al) * TS;
+    MAS_UNROLL for (int k = 0; k < NX; ++k) { o.Ai[k] = tile[eAi + k]; o.Aj[k] = tile[eAj + k]; o.Bi[k] = tile[eBi + k]; o.Bj[k] = tile[eBj + k]; }
+    o.lu = tile[elu]; o.lxx = tile[elxx]; o.lux = tile[elux];
+    if constexpr (!kMerged) { o.lx = tile[elx]; o.luu = tile[eluu]; }
+  }
+  __device__ __forceinline__ const RowTile& make(const Raw& r, int, RowTile&) const { return r; }
+  // step t's tile has arrived: if it was the last of its chunk, the helpers may reuse the slot
+  __device__ __forceinline__ void arrived(int t) const { if ((t & 3) == 0 && tid == 0) ctl->consumed[wave] = C - (t >> 2); }
+};
+
+// ---- models whose derivatives are all analytic (the identity LQR): every lane evaluates them in registers from x_t, u_t.  No
+// linearising helpers, no ring, no sweep: per step eight doubles are read instead of an 88-double tile.  The accepted trial is
+// committed by a FIFTH wavefront of the workgroup (fused_commit_wave), not by these lanes: their stores would be four-lane
+// partial-line writes, whose slow acknowledgements hold back the in-order counter the next step's operand loads retire
+// through (measured: 73 -> 111 us per launch on the identity LQR).
+template <class M>
+struct AnalyticSource {
+  using L = DerivLayout<M>;
+  static constexpr int NX = 4, NU = M::NU;
+  static constexpr bool kMerged = NU <= 2, kRequestLate = false;
+  static_assert(M::kAnalyticA && M::kAnalyticB && M::kAnalyticLx && M::kAnalyticLu && M::kAnalyticLxx && M::kAnalyticLuu && M::kAnalyticLux && !kMerged,
+                "every derivative analytic; the merged second round of NU <= 2 is not laid out here");
+  struct Raw { double x[NX], u[NU]; };
+  Dims d; const ModelParams* P; const double* Xsrc; const double* Usrc;
+  unsigned col; int a, lane, i, j, iu, ju;
+  __device__ __forceinline__ void begin() const {}
+  __device__ __forceinline__ void request(Raw& o, int t, bool) const {
+    MAS_UNROLL for (int q = 0; q < NX; ++q) o.x[q] = (Xsrc + (static_cast<size_t>(t) * NX + q) * d.Np)[col];
+    MAS_UNROLL for (int q = 0; q < NU; ++q) o.u[q] = (Usrc + (static_cast<size_t>(t) * NU + q) * d.Np)[col];
+  }
+  __device__ __forceinline__ RowTile make(const Raw& r, int t, RowTile&) const {
+    double Dl[L::ND];
+    linearise<M>(r.x, r.u, t, Dl, *P);
+    static_assert(NU == 4, "the picks below are written for 4 x 4 blocks");
+    auto at = [&](int base, int r0, int c) {                           // entry (r0, c) of a column-major 4 x 4 block of Dl, r0 and c lane-dependent
+      return pick4(c, pick4(r0, Dl[base], Dl[base + 1], Dl[base + 2], Dl[base + 3]), pick4(r0, Dl[base + 4], Dl[base + 5], Dl[base + 6], Dl[base + 7]),
+                   pick4(r0, Dl[base + 8], Dl[base + 9], Dl[base + 10], Dl[base + 11]), pick4(r0, Dl[base + 12], Dl[base + 13], Dl[base + 14], Dl[base + 15]));
+    };
+    RowTile o;
+    MAS_UNROLL for (int k = 0; k < NX; ++k) {                          // columns i, j of A (entries A(k, i)) and iu, ju of B
+      o.Ai[k] = pick4(i, Dl[L::oA + k], Dl[L::oA + 4 + k], Dl[L::oA + 8 + k], Dl[L::oA + 12 + k]);
+      o.Aj[k] = pick4(j, Dl[L::oA + k], Dl[L::oA + 4 + k], Dl[L::oA + 8 + k], Dl[L::oA + 12 + k]);
+      o.Bi[k] = pick4(iu, Dl[L::oB + k], Dl[L::oB + 4 + k], Dl[L::oB + 8 + k], Dl[L::oB + 12 + k]);
+      o.Bj[k] = pick4(ju, Dl[L::oB + k], Dl[L::oB + 4 + k], Dl[L::oB + 8 + k], Dl[L::oB + 12 + k]);
+    }
+    o.lx = pick4(i, Dl[L::oLx], Dl[L::oLx + 1], Dl[L::oLx + 2], Dl[L::oLx + 3]);
+    o.lu = pick4(iu, Dl[L::oLu], Dl[L::oLu + 1], Dl[L::oLu + 2], Dl[L::oLu + 3]);
+    o.lxx = at(L::oLxx, i, j);                                         // l_xx(i, j): element i + 4 j = this lane's
+    o.lux = at(L::oLux, iu, j);                                        // l_ux(iu, j)
+    o.luu = at(L::oLuu, iu, ju);                                       // l_uu(iu, ju)
+    return o;
+  }
+  __device__ __forceinline__ void arrived(int) const {}
+};
+
+// ---- the recursion of one backward wavefront (4 agents, 16 lanes each): mas_backward_row_kernel's step, operands from the LDS ring --
+template <class M, int BWD_BASE, int BWD_STRIDE, class Src>
+__device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelParams& P, double* __restrict__ lds, bool valid, Src& src,
+                                                    int wave, int a_base, const double* __restrict__ xT_src, unsigned xT_col, double* __restrict__ X_commit,
+                                                    double* __restrict__ kff, double* __restrict__ Kfb, long long* __restrict__ reg_events) {
+  constexpr int NX = 4, NU = M::NU;
   static_assert(M::NX == 4 && NU >= 1 && NU <= 4, "one DPP row = the 4 x 4 value Hessian");
   constexpr int LPA = 16, LL = 16;
   constexpr int oAtV = 0, oBtV = 16, oQxx = 32, oQux = 48, oL = 64, oVx = 80, oQx = 84, oPad = 96;
@@ -91,15 +190,14 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
   const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane;
   const int i = lane & 3, j = lane >> 2, iu = (i < NU) ? i : NU - 1, ju = (j < NU) ? j : NU - 1;
   const int al = wave * 4 + slot, a = a_base + al;
-  const bool valid = ctl->act[al] != 0;
-  double* T = lds + FL::oBwd + al * FL::kBwdStride;
-  const double* ring = lds + FL::oRing;
+  double* T = lds + BWD_BASE + al * BWD_STRIDE;
   auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
   // terminal boundary condition, ilqr.hpp:92-102: lane 0 evaluates it, every lane picks up its own entries
   if (lane == 0) {
     double xT[NX], vx[NX], vxx[NX * NX];
-    MAS_UNROLL for (int q = 0; q < NX; ++q) xT[q] = valid ? (xT_src + (static_cast<size_t>(d.T) * NX + q) * d.Np)[xT_col] : 0.0;
+    MAS_UNROLL for (int q = 0; q < NX; ++q) xT[q] = (valid || X_commit) ? (xT_src + (static_cast<size_t>(d.T) * NX + q) * d.Np)[xT_col] : 0.0;
+    if (X_commit) { MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X_commit, d.T * NX + q, a) = xT[q]; }      // (sources that commit while they read: x_T with the boundary condition)
     terminal_boundary<M>(xT, vx, vxx, P);
     MAS_UNROLL for (int q = 0; q < NX; ++q) T[oVx + q] = vx[q];
     MAS_UNROLL for (int q = 0; q < NX * NX; ++q) T[oQxx + q] = vxx[q];
@@ -108,33 +206,16 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
   double Vown = T[oQxx + lane], vxi = T[oVx + i];
   wave_sync();
 
-  // this lane's operands of one tile: element indices (the ring holds plain tiles, TS doubles apart)
-  int eAi = L::oA + 4 * i, eAj = L::oA + 4 * j, eBi = L::oB + 4 * iu, eBj = L::oB + 4 * ju;
-  int elx = L::oLx + i, elu = L::oLu + iu, elxx = L::oLxx + lane, elux = L::oLux + iu + NU * j, eluu = L::oLuu + iu + NU * ju;
-  // merged second round of pass 2 (NU <= 2), see mas_backward_row_kernel
+  // LDS row the second-round item of pass 2 reads (merged second round, NU <= 2: see mas_backward_row_kernel)
   const int item2 = (i < NU) ? 0 : ((i >= 2 && j < NU && i - 2 < NU) ? 1 : ((i >= 2 && j >= 2) ? 2 : 3));
   const int c2 = (i - 2) + 2 * (j - 2);
   int r_row2 = oBtV + iu * 4;
   if constexpr (kMerged) {
-    if (item2 == 0) { eBj = eAj; }
-    else if (item2 == 1) { eBj = L::oB + 4 * j; elux = L::oLuu + (i - 2) + NU * j; r_row2 = oBtV + (i - 2) * 4; }
-    else if (item2 == 2) { eBj = L::oA + 4 * c2; elux = L::oLx + c2; r_row2 = oVx; }
-    else { eBj = eAj; r_row2 = oBtV; }
+    if (item2 == 1) r_row2 = oBtV + (i - 2) * 4;
+    else if (item2 == 2) r_row2 = oVx;
+    else if (item2 == 3) r_row2 = oBtV;
   }
-  struct Tile { double Ai[NX], Aj[NX], Bi[NX], Bj[NX]; double lx, lu, lxx, lux, luu; };
-  const int C = (d.T + 3) >> 2;                                        // chunks of four time steps
-  // tile of step t: chunk n = C-1 - t/4 (the order the helpers produce them in), ring slot n % RING, tile (t & 3) * 16 + agent
-  auto fetch = [&](Tile& o, int t) {
-    const int n = C - 1 - (t >> 2);
-    const double* tile = ring + (static_cast<size_t>(n % RING) * 64 + static_cast<size_t>(t & 3) * 16 + al) * TS;
-    MAS_UNROLL for (int k = 0; k < NX; ++k) { o.Ai[k] = tile[eAi + k]; o.Aj[k] = tile[eAj + k]; o.Bi[k] = tile[eBi + k]; o.Bj[k] = tile[eBj + k]; }
-    o.lu = tile[elu]; o.lxx = tile[elxx]; o.lux = tile[elux];
-    if constexpr (!kMerged) { o.lx = tile[elx]; o.luu = tile[eluu]; }
-  };
-  auto acquire = [&](int t) {                                          // the chunk of step t lies complete in its slot
-    const int n = C - 1 - (t >> 2);
-    lds_wait(&ctl->ready[n % RING], [n](int v) { return v >= n + 1; }, error);
-  };
+  using Raw = typename Src::Raw;
   long long regs = 0;
   double rung_add[LL - 1];
   {
@@ -150,11 +231,17 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
   const int w_qux = (i < NU) ? (oQux + j * NU + i) : ((kMerged && item2 == 2) ? (oQx + c2) : (oPad + lane));
   const int w_vx = (j == 0) ? (oVx + i) : (oPad + lane);
 
-  Tile tA, tB;
-  acquire(d.T - 1);
-  fetch(tA, d.T - 1);
-  auto step = [&](int t, const Tile& c, Tile& nx) {
+  Raw tA, tB;
+  src.begin();
+  src.request(tA, d.T - 1, true);
+  auto step = [&](int t, const Raw& raw, Raw& nx) {
     MAS_UNROLL for (int m = 0; m < NU; ++m) { MAS_OPAQUE32(goff[m]); MAS_OPAQUE32(koff[m]); }
+    // UNCONDITIONAL (at t == 0 step 0 is requested again, unused): behind a branch the compiler must size the wait for these
+    // operands for the path WITHOUT the request -- eight operations fewer in flight -- and on the taken path that wait then
+    // includes the acknowledgement of the previous step's gain stores: measured +0.6 us per step on the identity LQR
+    if constexpr (!Src::kRequestLate) src.request(nx, t > 0 ? t - 1 : 0, false);
+    RowTile made;
+    const RowTile& c = src.make(raw, t, made);
     const double* Ai = c.Ai; const double* Aj = c.Aj; const double* Bi = c.Bi; const double* Bj = c.Bj;
 
     // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
@@ -182,10 +269,7 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
       MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
       // the next step's tile is requested HERE, behind the operand reads of pass 2 (an LDS queue serves one wavefront's
       // instructions in order): its ~20 reads travel in the shadow of passes 2 and 3 instead of in front of the wait above
-      if (t > 0) {
-        if (((t - 1) & 3) == 3) acquire(t - 1);                        // uniform: the next tile opens a new chunk
-        fetch(nx, t - 1);
-      }
+      if constexpr (Src::kRequestLate) src.request(nx, t > 0 ? t - 1 : 0, false);
       double s;
       s = sum_terms<NX>([&](int k) { return ra[k] * Aj[k]; });
       qxx_own = c.lxx + s;
@@ -315,7 +399,7 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
     }
     // the tile requested in pass 2 has arrived (pass 3 waited for every LDS operation): if it was the last of its chunk, the
     // helpers may reuse the slot
-    if (t > 0 && ((t - 1) & 3) == 0 && tid == 0) ctl->consumed[wave] = C - ((t - 1) >> 2);
+    if (t > 0) src.arrived(t - 1);
     kff_t -= static_cast<size_t>(NU) * d.Np; Kfb_t -= static_cast<size_t>(NU) * NX * d.Np;
   };
   int t = d.T - 1;
@@ -372,13 +456,33 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
   }
 }
 
+// ---- commit of the accepted trials of a workgroup's 16 agents by one wavefront (models without linearising helpers) ----
+// lane = (agent, row mod 4): a store instruction covers four rows of the 16 agents -- whole 128-byte lines when all of them commit
+template <class M>
+__device__ __forceinline__ void fused_commit_wave(const Dims& d, const FusedCtl* ctl, int a_base, double* __restrict__ X, double* __restrict__ U, const FusedRound& fr) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int l = static_cast<int>(threadIdx.x) & 63, al = l & 15, sub = l >> 4, a = a_base + al;
+  const int jsel = ctl->selj[al];
+  if (jsel < 0) return;                                                // (divergent: the other lanes go on)
+  const unsigned col = static_cast<unsigned>(ctl->col[al]);
+  auto copy_rows = [&](const double* __restrict__ src, double* __restrict__ dst, int rows) {
+    for (int r0 = 0; r0 < rows; r0 += 32) {                            // eight row groups in flight
+      double v[8];
+      MAS_UNROLL for (int q = 0; q < 8; ++q) { const int r = r0 + 4 * q + sub; if (r < rows) v[q] = (src + static_cast<size_t>(r) * d.Np)[col]; }
+      MAS_UNROLL for (int q = 0; q < 8; ++q) { const int r = r0 + 4 * q + sub; if (r < rows) MAS_AT(dst, r, a) = v[q]; }
+    }
+  };
+  copy_rows(fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * NX * d.Np, X, (d.T + 1) * NX);       // x = best_x; u = best_u, ilqr.hpp:231-232
+  copy_rows(fr.Us + static_cast<size_t>(jsel) * d.T * NU * d.Np, U, d.T * NU);
+}
+
 // grid = ceil(N / 16) workgroups of 64 * (4 + HELPERS) threads, FusedLayout::kBytes of dynamic LDS
 template <class M, int HELPERS, int RING>
-__global__ void __launch_bounds__(64 * (4 + HELPERS), 2)
+__global__ void __launch_bounds__(64 * (4 + HELPERS), HELPERS == 0 ? 1 : 2)   // (with helpers two wavefronts share a SIMD)
 mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, double* __restrict__ U, double* __restrict__ kff, double* __restrict__ Kfb,
                              long long* __restrict__ reg_events, FusedRound fr) {
   using FL = FusedLayout<M, HELPERS, RING>;
-  static_assert(RING >= 2 && RING <= 4 && HELPERS >= 1, "ring of chunk slots");
+  static_assert((RING >= 2 && RING <= 4 && HELPERS >= 1) || (RING == 0 && HELPERS <= 1), "ring of chunk slots");
   extern __shared__ double lds[];
   FusedCtl* ctl = reinterpret_cast<FusedCtl*>(lds + FL::oCtl);
   const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
@@ -407,6 +511,24 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
   const bool any_act = ctl->any_act != 0, any_pend = ctl->any_pend != 0;
   if (!any_act && !any_pend) return;
 
+  if constexpr (RING == 0) {
+    // every derivative analytic: the backward wavefronts evaluate them (AnalyticSource); a fifth wavefront commits
+    if (wave >= 4) {
+      if (any_pend) fused_commit_wave<M>(d, ctl, a_base, X, U, fr);
+      return;
+    }
+    if (!any_act) return;
+    const int slot = lane >> 4, al0 = wave * 4 + slot, a = a_base + al0;
+    const bool valid = ctl->act[al0] != 0;
+    if (__ballot(valid) == 0ull) return;
+    const int jsel = ctl->selj[al0];
+    const bool pend = jsel >= 0;
+    const double* Xsrc = pend ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * M::NX * d.Np : X;
+    const double* Usrc = pend ? fr.Us + static_cast<size_t>(jsel) * d.T * M::NU * d.Np : U;
+    const int l16 = lane & 15, i = l16 & 3, j = l16 >> 2;
+    AnalyticSource<M> src{d, &P, Xsrc, Usrc, static_cast<unsigned>(ctl->col[al0]), a, l16, i, j, (i < M::NU) ? i : M::NU - 1, (j < M::NU) ? j : M::NU - 1};
+    fused_backward_wave<M, FL::oBwd, FL::kBwdStride>(d, P, lds, valid, src, wave, a_base, Xsrc, src.col, nullptr, kff, Kfb, reg_events);
+  } else {
   if (wave < 4) {
     if (!any_act) return;
     const int al0 = wave * 4 + (lane >> 4);
@@ -419,10 +541,13 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
 #endif
     const int jsel = ctl->selj[al0];
     const double* xT_src = (jsel >= 0) ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * M::NX * d.Np : X;
-    fused_backward_wave<M, HELPERS, RING>(d, P, lds, ctl, wave, a_base, xT_src, static_cast<unsigned>(ctl->col[al0]), kff, Kfb, reg_events, fr.error);
+    const int l16 = lane & 15, i = l16 & 3, j = l16 >> 2;
+    RingSource<M, HELPERS, RING> src(lds, ctl, fr.error, wave, al0, d.T, l16, i, j, (i < M::NU) ? i : M::NU - 1, (j < M::NU) ? j : M::NU - 1);
+    fused_backward_wave<M, FL::oBwd, FL::kBwdStride>(d, P, lds, ctl->act[al0] != 0, src, wave, a_base, xT_src, static_cast<unsigned>(ctl->col[al0]), nullptr, kff, Kfb, reg_events);
   } else {
     __builtin_amdgcn_s_setprio(0);
     fused_helper_wave<M, HELPERS, RING>(d, P, lds, ctl, wave - 4, a_base, X, U, fr);
+  }
   }
 }
 

@@ -143,9 +143,11 @@ template <class M>
 class SolverImpl final : public SolverBase {
   static constexpr int NX = M::NX, NU = M::NU;
   static constexpr bool kConstrained = (M::NEQ + M::NIN) > 0;
-  // the two-kernel round of mas_fused_hip.hpp; NU <= 2: with NU = 4 the recursion alone fills the 256 VGPRs a wavefront may have
-  // when helper wavefronts share its SIMD (measured: 54 spilled registers, C4 17.3 -> 21.5 ms)
-  static constexpr bool kFusable = NX == 4 && NU <= 2 && !kConstrained;
+  // the two-kernel round of mas_fused_hip.hpp.  Finite-difference models: helper wavefronts linearise beside the recursion, NU <= 2
+  // only (with NU = 4 the recursion alone fills the 256 VGPRs a wavefront may have when helpers share its SIMD: 54 spilled
+  // registers, C4 17.3 -> 21.5 ms).  Models whose derivatives are all analytic: the recursion's lanes evaluate them in registers.
+  static constexpr bool kAllAnalytic = M::kAnalyticA && M::kAnalyticB && M::kAnalyticLx && M::kAnalyticLu && M::kAnalyticLxx && M::kAnalyticLuu && M::kAnalyticLux;
+  static constexpr bool kFusable = NX == 4 && !kConstrained && ((kAllAnalytic && NU == 4) || NU <= 2);
   using L = DerivLayout<M>;
 
  public:
@@ -457,7 +459,8 @@ class SolverImpl final : public SolverBase {
     bool staged_fused = false;
 #if !defined(MAS_HOST_EMULATION)
     if constexpr (kFusable) {
-      if (fused_enabled()) {            // the product's form of sweep + backward: the fused kernel, its tiles also dumped to the tile array
+      if (fused_enabled() && kFusedRing > 0) {            // the product's form of sweep + backward: the fused kernel, its tiles also dumped to the tile array
+                                                             // (all-analytic models form no tiles in the fused kernel: their staged access stays with the sweep kernel)
         FusedRound fr;
         fr.sel = SelectBody{}; fr.sel.active = active; fr.sel.alpha_sel = alpha_sel;
         fr.do_select = 0; fr.Xs = Xs; fr.Us = Us; fr.slot_prev = slot_of[0]; fr.D_dump = D; fr.error = fused_error;
@@ -891,7 +894,8 @@ class SolverImpl final : public SolverBase {
 #if defined(MAS_FUSED_HELPERS)
   static constexpr int kFusedHelpers = MAS_FUSED_HELPERS, kFusedRing = MAS_FUSED_RING;      // (A/B builds)
 #else
-  static constexpr int kFusedHelpers = (M::kAnalyticA && M::kAnalyticLxx) ? 2 : 4, kFusedRing = 2;
+  static constexpr bool kFusedAnalytic = kAllAnalytic && NU == 4;      // no tiles at all: AnalyticSource + one committing wavefront
+  static constexpr int kFusedHelpers = kFusedAnalytic ? 1 : ((M::kAnalyticA && M::kAnalyticLxx) ? 2 : 4), kFusedRing = kFusedAnalytic ? 0 : 2;
 #endif
   bool fused_enabled() const { return switches.fused; }
   double fused_bytes() const { return sweep_bytes() + backward_bytes(); }
