@@ -20,8 +20,10 @@ decoupled); RCCL is used only to take the MAX of the ranks' times and the SUM of
 c4, for the publish step of the Nash strategies (nash.hpp:66-71) timed separately as `solution_all_gather`.
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline     -- the linearisation sweep (the kernel north_star names): algorithmic bytes over the
-                  kernel's launch durations measured in this run with HIP events bound to each dispatch
+  roofline     -- the kernel that holds the linearisation sweep north_star names: for the four-state models the fused linearise +
+                  Riccati kernel (its tiles never reach HBM), else the sweep kernel itself; algorithmic bytes
+                  over the kernel's launch durations measured in this run with HIP events bound to each dispatch
+  unfused_round-- (c3, c4) the same steps with the five-kernel round: the gain of the fusion, and the sweep's own HBM roofline
   utilisation  -- backward / forward pass: issue %, wait %, LDS bank-conflict % (SQ counters cannot be read in-process:
                   taken from the committed rocprofv3 --pmc passes under profiles/, source stated)
   parity       -- the timed workload's result against the CPU oracle: exact vs its pure-IEEE-trig mode (the parity
@@ -44,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r2"    # profiles/<round>_pmc_traffic_<workload>.json, profiles/<round>_sq_counters_<workload>.json
+PROFILE_ROUND = "r3"    # profiles/<round>_pmc_traffic_<workload>.json, profiles/<round>_sq_counters_<workload>.json
 
 
 from multi_agent_solver_amd.dist import shard_range  # noqa: E402  contiguous ranges of the id-sorted block list, one per rank
@@ -54,16 +56,16 @@ M_SINGLE_TRACK, M_LQR, M_BICYCLE6 = 1, 2, 5
 WORKLOADS = {
     "c3": dict(name="multi_agent_single_track --solver ilqr --strategy sequential, 4096 agents per GPU, H=100 (BASELINE configs[2])",
                model=M_SINGLE_TRACK, nx=4, nu=2, agents=4096, T=100, dt=0.5, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=51392),
+               sweep_bytes_per_agent=51392, backward_bytes_per_agent=54432),
     "c2": dict(name="multi_agent_single_track --solver ilqr --strategy centralized, 256 agents, H=100 (BASELINE configs[1])",
                model=M_SINGLE_TRACK, nx=4, nu=2, agents=256, T=100, dt=0.5, strategy="centralized", max_outer=1, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=51392),
+               sweep_bytes_per_agent=51392, backward_bytes_per_agent=54432),
     "c4": dict(name="multi_agent_lqr --solver ilqr --strategy sequential, 4096 agents per GPU (32768 on 8), H=50 (BASELINE configs[3])",
                model=M_LQR, nx=4, nu=4, agents=4096, T=50, dt=0.1, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=38592),
+               sweep_bytes_per_agent=38592, backward_bytes_per_agent=8 * 50 * 88 + 32 + 8 * 50 * 20),
     "c5": dict(name="multi_agent_single_track --solver ilqr --strategy trustregion, nx=6 bicycle model, 8192 agents per GPU (65536 on 8), H=200 (BASELINE configs[4])",
                model=M_BICYCLE6, nx=6, nu=2, agents=8192, T=200, dt=0.25, strategy="trustregion", max_outer=10, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=185984),
+               sweep_bytes_per_agent=185984, backward_bytes_per_agent=8 * 200 * 108 + 48 + 8 * 200 * 14),
 }
 
 
@@ -93,7 +95,7 @@ def one_step(s, w):
     s.run(w["strategy"], w["max_outer"])
 
 
-def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier, after=None):
+def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier, after=None, unfused_reference=False):
     """Timed region: K steps with per-kernel instrumentation OFF (HIP events around every dispatch cost ~11 % of
     wall time on this latency-bound loop).  The kernel times / roofline come from a second pass of the same K
     steps, same process, same resident inputs, with the instrumentation ON."""
@@ -118,6 +120,27 @@ def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier, af
     st["profiled_pass_elapsed"] = time.perf_counter() - t1
     kt = s.kernel_times()
     s.set_profiling(False)
+    if unfused_reference:
+        # the same K steps with the five-kernel round (mas_hip_set_option "fused" 0; bit-identical results): what the fused round
+        # buys, measured in this very run, and the standalone linearisation sweep -- the HBM-bound kernel north_star names -- alone
+        s.set_option("fused", 0)
+        one_step(s, w)
+        s.reset_stats()
+        sync(); t2 = time.perf_counter()
+        for _ in range(steps):
+            one_step(s, w)
+        sync()
+        st["unfused_elapsed"] = time.perf_counter() - t2
+        st["unfused_agent_iterations"] = s.stats()["agent_iterations"]
+        s.reset_stats()
+        s.set_profiling(True)
+        for _ in range(steps):
+            one_step(s, w)
+        sync()
+        st["unfused_kernels"] = s.kernel_times()
+        s.set_profiling(False)
+        s.set_option("fused", 1)
+        one_step(s, w)                       # the solution read below is the product path's
     if after is not None:
         st["after"] = after(s)
     sol = s.solution()
@@ -143,15 +166,18 @@ def cpu_baseline(w, n_total):
     n = min(n_total, 64 * threads)
     stride = max(1, n_total // n)
     x0 = initial_states(w, n_total, 0, n_total)[::stride][:n]
-    its, el, reps = 0, 0.0, 0
-    while el < 8.0 and reps < 20:            # bounded: about 10 s of CPU work
+    rates, el = [], 0.0
+    while (el < 8.0 or len(rates) < 3) and len(rates) < 20:            # bounded: about 10 s of CPU work, at least three repeats
         t0 = time.perf_counter()
         r = oracle_run(w, x0, "libm", threads)      # std::sin/cos/tan, as the reference binary calls them
-        el += time.perf_counter() - t0
-        its += int(r["stats"]["total_iterations"]) * (x0.shape[0] if w["strategy"] == "centralized" else 1)
-        reps += 1
-    return dict(value=its / el, unit="agent-iterations/s", cores=threads, kind="port",
-                sample=f"{x0.shape[0]} agents (every {stride}th of {n_total}), full '{w['strategy']}' strategy run repeated {reps}x, {el:.1f} s total; "
+        dt = time.perf_counter() - t0
+        el += dt
+        rates.append(int(r["stats"]["total_iterations"]) * (x0.shape[0] if w["strategy"] == "centralized" else 1) / dt)
+    rates.sort()
+    median = rates[len(rates) // 2] if len(rates) % 2 else 0.5 * (rates[len(rates) // 2 - 1] + rates[len(rates) // 2])
+    return dict(value=median, unit="agent-iterations/s", cores=threads, kind="port", statistic="median of the repeats", repeats=len(rates),
+                min=rates[0], max=rates[-1], spread_rel=(rates[-1] - rates[0]) / median,
+                sample=f"{x0.shape[0]} agents (every {stride}th of {n_total}), full '{w['strategy']}' strategy run repeated {len(rates)}x, {el:.1f} s total; "
                        f"CPU restatement of reference algorithm (oracle/, gcc -O2 -ffp-contract=off, OpenMP schedule(static) over agents as nash.hpp:59, glibc trig)")
 
 
@@ -187,6 +213,25 @@ def parity_block(w, sol, n_total, max_agents=4096):
                            "north_star_tolerance_1e-5_met": bool(rel.max() <= 1e-5)},
         "oracle_seconds": round(time.perf_counter() - t0, 2),
     }
+    if w["model"] == M_SINGLE_TRACK and w["strategy"] == "sequential" and stride == 1:
+        # the tolerance that can be true (tests/test_population_tolerance.py): the GPU result's population
+        # statistics against every faithful variant of the CPU arithmetic, all agents
+        from oracle import oracle as O
+        from oracle.population import POPULATION_BOUNDS_512, POPULATION_BOUNDS_4096, VARIANTS, oracle_variant, population_deviation, population_statistics
+        bounds = POPULATION_BOUNDS_4096 if idx.size >= 2048 else POPULATION_BOUNDS_512      # (a smaller population is noisier)
+        mine = population_statistics({"cost": sol["cost"][idx], "iters": sol["iters"][idx], "status": sol["status"][idx]})
+        worst, per = {k: 0.0 for k in bounds}, {}
+        for name, kw in VARIANTS.items():
+            dev = population_deviation(mine, population_statistics(oracle_variant(O, x0, T=w["T"], dt=w["dt"], **kw)))
+            per[name] = {k: float(v) for k, v in dev.items()}
+            for k, v in dev.items():
+                worst[k] = max(worst[k], float(v))
+        out["population_tolerance"] = {
+            "statement": "total cost, mean iterations, converged fraction and the 10/25/50/75/90 % quantiles of the per-agent cost of the GPU result against the CPU "
+                         "restatement under glibc trig / Eigen-style pairwise product sums / non-aliased symmetrisation / one-ulp inputs / all of them (the per-agent 1e-5 is "
+                         "unattainable: one rounding anywhere moves single agents by per cents)",
+            "agents": int(idx.size), "bounds": bounds, "worst_over_variants": worst, "per_variant": per,
+            "met": bool(all(worst[k] <= bounds[k] for k in bounds))}
     if w["strategy"] == "centralized":
         out["vs_reference_stacked_solve"] = ("NOT the same number: the reference finite-differences the summed cost of the stacked problem "
                                              "(centralized.hpp:18-38, multi_agent_problem.hpp:94-122), whose Hessians carry FD noise in the cross-agent blocks; "
@@ -197,29 +242,52 @@ def parity_block(w, sol, n_total, max_agents=4096):
 
 
 def _load_profile(kind, workload):
+    """a committed counter summary, or (None, reason) when there is none or it was collected from OTHER kernel sources than
+    the ones this library is built from (multi_agent_solver_amd/source_hash.py): stale counters are never quoted"""
+    from multi_agent_solver_amd.source_hash import source_hash
     path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{kind}_{workload}.json")
+    rel = os.path.relpath(path, ROOT)
     try:
-        return json.load(open(path)), os.path.relpath(path, ROOT)
+        prof = json.load(open(path))
     except (OSError, ValueError):
-        return None, None
+        return None, f"{rel}: not collected"
+    have, want = prof.get("source_hash"), source_hash()
+    if have != want:
+        return None, f"{rel}: collected from other kernel sources (source_hash {have} != {want}); re-run tools/collect_profiles.sh {workload}"
+    return prof, rel
 
 
-def roofline_of(kt, w, workload, name="sweep"):
+ROOFLINE_KERNELS = {
+    # name in kernel_times -> (kernel symbol, what its algorithmic bytes are, what bounds it)
+    "linearise_riccati": ("mas_linearise_riccati_kernel",
+                          "SURVEY.md 8(d), linearisation sweep + backward pass: read 8[(nx+nu)T+nx] + write 8[T*ND+nx+nx^2] (the sweep), read 8[T*ND+nx] + write 8T(nu+nu*nx) (the recursion).  "
+                          "The fused kernel keeps the derivative tiles in LDS (or, for analytic models, in registers): they never reach HBM, so `traffic` is a fraction of these bytes",
+                          "the recursion's dependent FP64 chain (one wavefront per SIMD, DESIGN.md section 4); quoted against HBM as the contract prescribes"),
+    "sweep": ("mas_sweep_kernel",
+              "SURVEY.md 8(d): read 8[(nx+nu)T+nx] + write 8[T*ND+nx+nx^2]; the kernel itself moves 8(2nx+nx^2) B less per agent (x_T, terminal v_x/v_xx belong to the backward kernel)",
+              "HBM (streaming store of the derivative tiles)"),
+}
+
+
+def roofline_of(kt, w, workload, name=None):
     """achieved = algorithmic bytes (SURVEY.md 8(d) per agent x active agents of each launch) / launch durations.
-    `frac` uses the HIP events bound to each dispatch of the instrumented pass (every launch of the kernel, including
-    the empty run-ahead launch at the end of each solve) -- the quantity rocprofv3 --kernel-trace averages, so
-    profiles/*_kernel_stats.csv can be held against it.  `inkernel_span` is the same sum over the kernel's own
-    first-workgroup-start .. last-workgroup-end REFCLK stamps (no dispatch ramp)."""
+    Kernel: the fused linearise + Riccati kernel where the round is fused (four-state models), else the linearisation sweep.
+    `frac` uses the HIP events bound to each dispatch of the instrumented pass (every launch of the kernel) -- the quantity
+    rocprofv3 --kernel-trace averages, so profiles/*_kernel_stats.csv can be held against it.  `inkernel_span` (sweep only) is
+    the same sum over the kernel's own first-workgroup-start .. last-workgroup-end REFCLK stamps (no dispatch ramp)."""
+    if name is None:
+        name = "linearise_riccati" if kt.get("linearise_riccati", {}).get("launches") else "sweep"
     k = kt.get(name)
     if not k or k["launches"] == 0 or k["total_ms"] <= 0:
         return None
+    symbol, what, bound_by = ROOFLINE_KERNELS[name]
     achieved = k["algorithmic_bytes"] / (k["total_ms"] * 1e-3) / 1e9
-    out = dict(bound="hbm", kernel="mas_sweep_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+    out = dict(bound="hbm", kernel=symbol, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                timing="HIP events bound to each dispatch (hipExtLaunchKernelGGL), all launches of the instrumented pass",
                launches=k["launches"], avg_launch_us=1e3 * k["total_ms"] / k["launches"],
                algorithmic_bytes_per_launch=k["algorithmic_bytes"] / k["launches"],
-               algorithmic_bytes_per_agent=w["sweep_bytes_per_agent"],
-               algorithmic_bytes_note="SURVEY.md 8(d): read 8[(nx+nu)T+nx] + write 8[T*ND+nx+nx^2]; the kernel itself moves 8(2nx+nx^2) B less per agent (x_T, terminal v_x/v_xx belong to the backward kernel)")
+               algorithmic_bytes_per_agent=(w["sweep_bytes_per_agent"] + w["backward_bytes_per_agent"]) if name == "linearise_riccati" else w["sweep_bytes_per_agent"],
+               algorithmic_bytes_note=what, limited_by=bound_by)
     ik = kt.get(name + "_inkernel")
     if ik and ik["launches"] and ik["total_ms"] > 0:
         a = ik["algorithmic_bytes"] / (ik["total_ms"] * 1e-3) / 1e9
@@ -231,14 +299,15 @@ def roofline_of(kt, w, workload, name="sweep"):
                                         timing="in-kernel span", note="launches in which every agent of the batch is still active (first round of each solve): the kernel at its design point")
     # HBM traffic: PMC counters cannot be read from inside this process.  DERIVED figure: the measured/algorithmic ratio of
     # the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, corrected as MI355X_MICROARCH.md
-    # prescribes: FETCH_SIZE x2 on gfx950) applied to this run's algorithmic bytes per launch.  None without the profile.
+    # prescribes: FETCH_SIZE x2 on gfx950) applied to this run's algorithmic bytes per launch.  null (with the reason) without a
+    # profile collected from exactly these kernel sources.
     pmc, src = _load_profile("pmc_traffic", workload)
-    out["traffic"], out["traffic_source"] = None, None
-    if pmc and "sweep" in pmc.get("kernels", {}):
-        ratio = pmc["kernels"]["sweep"].get("measured_over_algorithmic")
+    out["traffic"], out["traffic_source"] = None, src
+    if pmc and name in pmc.get("kernels", {}):
+        ratio = pmc["kernels"][name].get("measured_over_algorithmic")
         if ratio:
             out["traffic"] = ratio * out["algorithmic_bytes_per_launch"]
-            out["traffic_source"] = f"derived: {src} (FETCH_SIZE x2 + WRITE_SIZE = {ratio:.4f} x algorithmic bytes over the launches of one strategy run; collected at {pmc.get('commit', 'unknown commit')})"
+            out["traffic_source"] = f"derived: {src} (FETCH_SIZE x2 + WRITE_SIZE = {ratio:.4f} x algorithmic bytes over the launches of one strategy run; collected at {pmc.get('commit', 'unknown commit')}, source_hash {pmc.get('source_hash')})"
     return out
 
 
@@ -248,9 +317,9 @@ def utilisation_of(workload):
     reference's SSE2 rounding)."""
     sq, src = _load_profile("sq_counters", workload)
     if not sq:
-        return None
-    out = {"source": f"{src} (rocprofv3 --pmc, SQ counters of one strategy run; collected at {sq.get('commit', 'unknown commit')})"}
-    for name in ("backward", "central_backward", "forward", "sweep"):
+        return {"source": None, "reason": src}
+    out = {"source": f"{src} (rocprofv3 --pmc, SQ counters of one strategy run; collected at {sq.get('commit', 'unknown commit')}, source_hash {sq.get('source_hash')})"}
+    for name in ("linearise_riccati", "backward", "central_backward", "forward", "sweep"):
         k = sq.get("kernels", {}).get(name)
         if k and "derived" in k:
             out[name] = k["derived"]
@@ -267,6 +336,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the A/B pass with the five-kernel round (c3 / c4, N = 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for a single rank (exercises the RCCL path on one GPU)")
     ap.add_argument("--gather-solution", action="store_true",
@@ -319,7 +389,8 @@ def main():
             return {"ms": 1e3 * min(times), "bytes_received_per_rank": nbytes, "GBs_per_rank": nbytes / min(times) / 1e9, "collective": "all_gather x3 (X, U, cost)",
                     "what": "publish step of the Nash strategies (update_initial_with_best, nash.hpp:66-71): every rank receives every agent's trajectory; "
                             "off the timed path because decoupled agents (every shipped example) do not consume it"}
-    elapsed, st, kt, sol = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier, after=gather)
+    elapsed, st, kt, sol = measure(w, hi - lo, lo, n_total, device, args.steps, args.warmup, sync, barrier, after=gather,
+                                   unfused_reference=(world == 1 and not args.no_unfused and args.workload in ("c3", "c4")))
     vals = torch.tensor([elapsed, float(st["agent_iterations"]), float(st["converged_solves"]), float(st["solves"])],
                         dtype=torch.float64, device=("cuda" if args.backend == "nccl" else "cpu"))
     if dist is not None:
@@ -345,7 +416,7 @@ def main():
             "converged_agent_trajectories_per_sec": (n_total * args.steps) / elapsed if w["strategy"] != "centralized" else None,
             "agent_iterations_per_step": iters / args.steps,
             "converged_solves_fraction": conv / max(1.0, solves),
-            "roofline": roofline_of(kt, w, args.workload, "sweep"),
+            "roofline": roofline_of(kt, w, args.workload),
             "utilisation": utilisation_of(args.workload),
             "kernels": kernels,
             "kernel_time_fraction_of_wall": total_kernel_ms * 1e-3 / st["profiled_pass_elapsed"],
@@ -353,6 +424,15 @@ def main():
         }
         if st.get("after") is not None:
             out["solution_all_gather"] = st["after"]
+        if "unfused_elapsed" in st:
+            uk = st["unfused_kernels"]
+            out["unfused_round"] = {
+                "what": "the same K steps with the five-kernel round (sweep -> backward -> line search -> select -> commit; mas_hip_set_option 'fused' 0), same process, "
+                        "same resident inputs, bit-identical results (tests/test_gpu_parity.py): what the two-kernel round buys, and the linearisation sweep as a kernel of its own",
+                "ms_per_step": 1e3 * st["unfused_elapsed"] / args.steps, "value": st["unfused_agent_iterations"] / st["unfused_elapsed"],
+                "speedup_of_the_fused_round": st["unfused_elapsed"] / elapsed,
+                "kernels_avg_us": {n: round(1e3 * k["total_ms"] / max(1, k["launches"]), 2) for n, k in uk.items() if "_inkernel" not in n},
+                "roofline_sweep": roofline_of(uk, w, args.workload, "sweep")}
         out["parity"] = parity_block(w, sol, n_total) if (world == 1 and not args.no_parity) else None
         out["cpu_baseline"] = cpu_baseline(w, n_total) if (world == 1 and not args.no_cpu_baseline) else None
         if world == 1 and not args.no_also and args.workload == "c3":

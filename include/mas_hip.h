@@ -174,6 +174,32 @@ int mas_hip_run_centralized_dense(mas_hip_solver*);
 typedef int (*mas_hip_cost_exchange_fn)(void* ctx, const double* local_costs, int32_t n_local, double* global_total);
 int mas_hip_set_cost_exchange(mas_hip_solver*, mas_hip_cost_exchange_fn fn, void* ctx);
 
+/* ---- agents sharded over the GPUs of a node: RCCL inside the library ----
+ * Replaces the OpenMP fan-out over agents of strategies/nash.hpp:59-71 across devices: the id-sorted block list
+ * (multi_agent_problem.hpp:37-50) is cut into contiguous ranges (mas_hip_shard_range), one handle per GPU -- one process per GPU
+ * (mas_hip_comm_create, ids handed around by the launcher) or one process driving several GPUs from one thread each
+ * (mas_hip_comm_create_all).  librccl.so.1 is opened on first use; nothing else in this header needs it.  The sequential and
+ * trust-region strategies exchange nothing (agents are decoupled in every shipped example); the two exchanges that exist:
+ *   mas_hip_all_gather_solution     the publish step (update_initial_with_best for coupled costs, nash.hpp:66-71): every rank
+ *                                   receives every agent's trajectory, [n_total][T+1][nx] / [n_total][T][nu] / [n_total] DEVICE buffers in
+ *                                   the reference layout; the shard is converted on the device straight to its displacement and travels
+ *                                   as one collective per array (ncclAllGather; uneven shards: grouped broadcasts, nothing padded)
+ *   mas_hip_set_comm_cost_exchange  run_line_search's total cost over ALL agents (nash.hpp:45-49,119,134-143): the shards' costs are
+ *                                   all-gathered and summed by one wavefront in global block order on every rank -- bit for bit
+ *                                   the total one handle holding all agents forms, so every rank takes the same decisions, and no
+ *                                   cost leaves the device.  Takes precedence over nothing: clear the host callback first.
+ * A communicator is bound to the device it was created on and must outlive the handles that use it. */
+typedef struct mas_hip_comm mas_hip_comm;
+#define MAS_HIP_COMM_ID_BYTES 128
+int mas_hip_comm_unique_id(void* id_out /* MAS_HIP_COMM_ID_BYTES */);                               /* ncclGetUniqueId: one rank, then to the others by any channel */
+int mas_hip_comm_create(const void* id, int n_ranks, int rank, int device, mas_hip_comm** out);     /* ncclCommInitRank (collective over the ranks) */
+int mas_hip_comm_create_all(int n_devices, const int* devices, mas_hip_comm** out /* [n_devices] */);   /* ncclCommInitAll: one process, several GPUs */
+int mas_hip_comm_destroy(mas_hip_comm*);
+const char* mas_hip_comm_last_error(void);
+void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi);                       /* contiguous id ranges, sizes differ by at most one */
+int mas_hip_all_gather_solution(mas_hip_solver*, mas_hip_comm*, int n_total, void* X_all_dev, void* U_all_dev, void* cost_all_dev);   /* any buffer may be NULL */
+int mas_hip_set_comm_cost_exchange(mas_hip_solver*, mas_hip_comm* /* NULL: local sum */, int n_total);
+
 /* ---- results: OCP::best_states/best_controls/best_cost; Solution (solution.hpp:9-15) ---- */
 int mas_hip_get_solution_host(mas_hip_solver*, double* X /* [N][T+1][nx] */, double* U /* [N][T][nu] */,
                               double* cost /* [N] */, int32_t* iterations /* [N] */, int32_t* exit_status /* [N] */);

@@ -29,6 +29,8 @@ EXPORTS = [
     "mas_hip_get_solution_host", "mas_hip_get_solution_device", "mas_hip_total_cost",
     "mas_hip_set_cost_exchange", "mas_hip_get_trust_radii_host", "mas_hip_debug_backward_host",
     "mas_hip_get_stats", "mas_hip_reset_stats", "mas_hip_set_profiling", "mas_hip_get_kernel_times",
+    "mas_hip_comm_unique_id", "mas_hip_comm_create", "mas_hip_comm_create_all", "mas_hip_comm_destroy", "mas_hip_comm_last_error",
+    "mas_hip_shard_range", "mas_hip_all_gather_solution", "mas_hip_set_comm_cost_exchange",
 ]
 
 
@@ -111,6 +113,15 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     lib.mas_hip_debug_backward_host.argtypes = [vp, d, d, d, C.POINTER(C.c_int64)]
     lib.mas_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.mas_hip_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
+    lib.mas_hip_comm_unique_id.argtypes = [vp]
+    lib.mas_hip_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mas_hip_comm_create_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    lib.mas_hip_comm_destroy.argtypes = [vp]
+    lib.mas_hip_comm_last_error.restype = C.c_char_p
+    lib.mas_hip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mas_hip_shard_range.restype = None
+    lib.mas_hip_all_gather_solution.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    lib.mas_hip_set_comm_cost_exchange.argtypes = [vp, vp, C.c_int]
     return lib
 
 

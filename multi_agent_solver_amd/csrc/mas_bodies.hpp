@@ -661,14 +661,28 @@ struct TrustCopyBody {
   }
 };
 
+// Joint step of detail::run_line_search (nash.hpp:92-180) decided ON THE DEVICE.  The reference compares sums of ALL agents' costs
+// (compute_total_cost, nash.hpp:45-49): base_cost before, new_cost after the solves, trial_cost after every blended rollout.  The
+// sums are formed by one wavefront in block order (wave_serial_sum, mas_central.hpp: the serial loop's rounding) and the decisions
+// are kept in JointState, so the alpha ladder needs no read-back: every blend / sum pair is enqueued, and the pairs behind the
+// accepted one find `accepted` set and do nothing.
+struct JointState {
+  double base;         // base_cost
+  double last_total;   // the sum formed last
+  int need_blend;      // new_cost >= base_cost: the alpha ladder runs (nash.hpp:121-123)
+  int accepted;        // a blended step with trial_cost < base_cost was found (nash.hpp:144-158)
+};
+
 // Nash line-search blend, nash.hpp:134-142: U_trial = U_old + alpha (U_cand - U_old), roll out, cost
 template <class M>
 struct BlendRolloutBody {
   Dims d; double dt; double alpha; ModelParams P;
   const double* x0; const double* U_old; const double* U_cand;
   double* X_trial; double* U_trial; double* cost_trial;
+  const JointState* st = nullptr;     // non-null: skip unless the ladder is running and nothing was accepted yet
   MAS_HD void operator()(int a) const {
     constexpr int NX = M::NX, NU = M::NU;
+    if (st && (!st->need_blend || st->accepted)) return;
     double x[NX], xn[NX], u[NU];
     MAS_UNROLL for (int i = 0; i < NX; ++i) { x[i] = MAS_AT(x0, i, a); MAS_AT(X_trial, i, a) = x[i]; }
     double c = 0.0;
@@ -684,6 +698,20 @@ struct BlendRolloutBody {
     }
     c += M::terminal_cost(x, P);
     cost_trial[a] = c;
+  }
+};
+
+// no blended step was accepted: back to the trajectories of before the solves (nash.hpp:160-176)
+template <class M>
+struct RevertBody {
+  Dims d; const JointState* st;
+  double* X; double* U; double* cost; const double* X_old; const double* U_old; const double* cost_old;
+  MAS_HD void operator()(int a, int t) const {
+    constexpr int NX = M::NX, NU = M::NU;
+    if (!st->need_blend || st->accepted) return;
+    MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(X, t * NX + i, a) = MAS_AT(X_old, t * NX + i, a);
+    if (t < d.T) { MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(U, t * NU + i, a) = MAS_AT(U_old, t * NU + i, a); }
+    if (t == 0) cost[a] = cost_old[a];              // objective(old) == the stored old cost
   }
 };
 

@@ -10,6 +10,8 @@
 
 #include "mas_solver.hpp"
 
+struct mas_hip_comm { mas::Comm c; };
+
 struct mas_hip_solver {
   std::unique_ptr<mas::SolverBase> impl;
   int N = 0, T = 0;
@@ -64,6 +66,17 @@ int create_impl(const mas_hip_problem_desc* desc, void* stream, mas_hip_solver**
     g_create_error = e.what();
     return MAS_HIP_ERR_RUNTIME;
   }
+}
+thread_local std::string g_comm_error;
+template <class Fn>
+int comm_guarded(Fn&& fn) {
+  try {
+    mas::RcclApi& api = mas::RcclApi::get();
+    if (!api.ok()) { g_comm_error = api.error.empty() ? "librccl not available" : api.error; return MAS_HIP_ERR_RUNTIME; }
+    fn(api);
+    return MAS_HIP_OK;
+  } catch (const std::invalid_argument& e) { g_comm_error = e.what(); return MAS_HIP_ERR_INVALID;
+  } catch (const std::exception& e) { g_comm_error = e.what(); return MAS_HIP_ERR_RUNTIME; }
 }
 }  // namespace
 
@@ -133,6 +146,66 @@ int mas_hip_total_cost(mas_hip_solver* h, double* total) {
 }
 int mas_hip_set_cost_exchange(mas_hip_solver* h, mas_hip_cost_exchange_fn fn, void* ctx) {
   return guarded(h, [&](mas::SolverBase& s) { s.cost_exchange = fn; s.cost_exchange_ctx = ctx; });
+}
+// ---- RCCL communicators (mas_rccl.hpp) ----
+const char* mas_hip_comm_last_error(void) { return g_comm_error.c_str(); }
+int mas_hip_comm_unique_id(void* id_out) {
+  if (!id_out) return MAS_HIP_ERR_INVALID;
+  return comm_guarded([&](mas::RcclApi& api) {
+    mas::ncclUniqueId id;
+    const int rc = api.GetUniqueId(&id);
+    if (rc != mas::kNcclSuccess) throw std::runtime_error(std::string("ncclGetUniqueId failed: ") + api.GetErrorString(rc));
+    std::memcpy(id_out, id.internal, sizeof(id.internal));
+  });
+}
+int mas_hip_comm_create(const void* id, int n_ranks, int rank, int device, mas_hip_comm** out) {
+  if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MAS_HIP_ERR_INVALID;
+  *out = nullptr;
+  return comm_guarded([&](mas::RcclApi& api) {
+    MAS_HIP_CHECK(hipSetDevice(device));
+    mas::ncclUniqueId uid;
+    std::memcpy(uid.internal, id, sizeof(uid.internal));
+    auto c = std::make_unique<mas_hip_comm>();
+    c->c.n_ranks = n_ranks; c->c.rank = rank; c->c.device = device;
+    c->c.check(api.CommInitRank(&c->c.comm, n_ranks, uid, rank), "ncclCommInitRank");
+    *out = c.release();
+  });
+}
+int mas_hip_comm_create_all(int n_devices, const int* devices, mas_hip_comm** out) {
+  if (!out || n_devices < 1) return MAS_HIP_ERR_INVALID;
+  return comm_guarded([&](mas::RcclApi& api) {
+    std::vector<int> devs(n_devices);
+    for (int i = 0; i < n_devices; ++i) devs[i] = devices ? devices[i] : i;
+    std::vector<mas::ncclComm_t> comms(n_devices, nullptr);
+    mas::Comm probe;
+    probe.check(api.CommInitAll(comms.data(), n_devices, devs.data()), "ncclCommInitAll");
+    for (int i = 0; i < n_devices; ++i) {
+      out[i] = new mas_hip_comm();
+      out[i]->c.comm = comms[i]; out[i]->c.n_ranks = n_devices; out[i]->c.rank = i; out[i]->c.device = devs[i];
+    }
+  });
+}
+int mas_hip_comm_destroy(mas_hip_comm* c) {
+  if (!c) return MAS_HIP_ERR_INVALID;
+  const int rc = comm_guarded([&](mas::RcclApi& api) { if (c->c.comm) c->c.check(api.CommDestroy(c->c.comm), "ncclCommDestroy"); });
+  delete c;
+  return rc;
+}
+void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi) {
+  int a = 0, b = 0;
+  if (n_ranks > 0 && rank >= 0 && rank < n_ranks) mas::shard_range(n_total, n_ranks, rank, &a, &b);
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+}
+int mas_hip_all_gather_solution(mas_hip_solver* h, mas_hip_comm* c, int n_total, void* X_all, void* U_all, void* cost_all) {
+  if (!c) return MAS_HIP_ERR_INVALID;
+  return guarded(h, [&](mas::SolverBase& s) {
+    if (!mas::RcclApi::get().ok()) throw std::runtime_error("librccl not available: " + mas::RcclApi::get().error);
+    s.all_gather_solution(&c->c, n_total, static_cast<double*>(X_all), static_cast<double*>(U_all), static_cast<double*>(cost_all));
+  });
+}
+int mas_hip_set_comm_cost_exchange(mas_hip_solver* h, mas_hip_comm* c, int n_total) {
+  return guarded(h, [&](mas::SolverBase& s) { s.set_comm_exchange(c ? &c->c : nullptr, n_total); });
 }
 int mas_hip_get_trust_radii_host(mas_hip_solver* h, double* radii) {
   if (!radii) return MAS_HIP_ERR_INVALID;

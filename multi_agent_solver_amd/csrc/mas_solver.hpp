@@ -24,6 +24,7 @@
 #if !defined(MAS_HOST_EMULATION)
 #include "mas_kernels_hip.hpp"
 #include "mas_fused_hip.hpp"
+#include "mas_rccl.hpp"
 #endif
 
 namespace mas {
@@ -83,6 +84,9 @@ class SolverBase {
   using CostExchange = int (*)(void* ctx, const double* local_costs, int32_t n_local, double* global_total);
   CostExchange cost_exchange = nullptr;
   void* cost_exchange_ctx = nullptr;
+  // agents sharded over GPUs with RCCL inside the library (mas_hip_set_comm_cost_exchange / mas_hip_all_gather_solution)
+  virtual void set_comm_exchange(void* comm, int n_total) = 0;
+  virtual void all_gather_solution(void* comm, int n_total, double* X_all, double* U_all, double* cost_all) = 0;
 
   // Which of several BIT-IDENTICAL kernel forms a launch uses (tests hold the forms against each other; tools/ measures them).
   // Defaults are the measured best.  Set through mas_hip_set_option; a build with -DMAS_HIP_ENV_SWITCHES (experiments only,
@@ -196,7 +200,7 @@ class SolverImpl final : public SolverBase {
     try { be.sync(); } catch (...) {}
     if (round_events_made) for (auto& e : round_ev) be.drop_event(e);
     for (void* p : allocations) be.free(p);
-    be.free_pinned(host_counters); be.free_pinned(host_central);
+    be.free_pinned(host_counters); be.free_pinned(host_central); if (host_joint) be.free_pinned(host_joint);
     be.destroy();
   }
 
@@ -312,6 +316,30 @@ class SolverImpl final : public SolverBase {
     Timer tm(*this);
     ensure_initialized();
     ensure_snapshots();
+    if (cost_exchange) { run_line_search_host_exchange(max_outer); return; }
+    // The joint step is decided on the device (JointState): total costs by one wavefront in block order -- over every rank's agents
+    // after an RCCL all-gather of the shards' costs when the block list is sharded (set_comm_exchange) -- and ONE read-back per
+    // outer iteration (does the alpha ladder run at all?); the ladder's nine blend / sum pairs are enqueued without the host.
+    if (!joint) { joint = static_cast<JointState*>(raw_alloc(sizeof(JointState))); host_joint = static_cast<JointState*>(be.alloc_pinned(sizeof(JointState))); }
+    joint_sum_device(JointSumBody::kBase);
+    for (int outer = 0; outer < max_outer; ++outer) {
+      be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
+      be.d2d(cost_old, cost, sizeof(double) * d.Np);
+      solve_all();
+      joint_sum_device(JointSumBody::kAfterSolves);
+      be.d2h(host_joint, joint, sizeof(JointState));
+      if (!host_joint->need_blend) continue;
+      be.d2d(U_cand, U, sizeof(double) * d.T * NU * d.Np);
+      for (double alpha = 0.5; alpha > 1e-3; alpha *= 0.5) {             // nash.hpp:126-159
+        be.template launch_1d<1>("blend_rollout", BlendRolloutBody<M>{d, dt, alpha, P, x0, U_old, U_cand, X, U, cost, joint}, d.N);
+        joint_sum_device(JointSumBody::kAfterTrial);
+      }
+      be.template launch_2d<4>("revert", RevertBody<M>{d, joint, X, U, cost, X_old, U_old, cost_old}, d.N, d.T + 1);
+    }
+    last_total_valid = false;
+  }
+  // the same strategy with the total cost formed by the caller's host callback (mas_hip_set_cost_exchange: torch.distributed / gloo)
+  void run_line_search_host_exchange(int max_outer) {
     double base_cost = joint_sum(cost);
     for (int outer = 0; outer < max_outer; ++outer) {
       be.d2d(X_old, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(U_old, U, sizeof(double) * d.T * NU * d.Np);
@@ -334,6 +362,50 @@ class SolverImpl final : public SolverBase {
       } else base_cost = new_cost;
     }
     last_total_valid = false;
+  }
+  // sum of all agents' costs in global block order + the decision of `mode`, on the stream
+  void joint_sum_device(int mode) {
+    const double* costs = cost; int n = d.N;
+#if !defined(MAS_HOST_EMULATION)
+    if (comm_exchange) {
+      int lo = 0, hi = 0; shard_range(comm_total, comm_exchange->n_ranks, comm_exchange->rank, &lo, &hi);
+      be.d2d(comm_costs + lo, cost, sizeof(double) * d.N);
+      comm_exchange->all_gather_shards(comm_costs, comm_total, 1, be.cur);
+      costs = comm_costs; n = comm_total;
+    }
+#endif
+    be.launch_group("joint_sum", JointSumBody{costs, n, joint, mode}, 64);
+  }
+  void set_comm_exchange(void* comm, int n_total) override {
+#if !defined(MAS_HOST_EMULATION)
+    comm_exchange = static_cast<Comm*>(comm);
+    if (comm_exchange) {
+      int lo = 0, hi = 0; shard_range(n_total, comm_exchange->n_ranks, comm_exchange->rank, &lo, &hi);
+      if (hi - lo != d.N) { comm_exchange = nullptr; throw std::invalid_argument("this handle's agent count is not the shard size of its rank"); }
+      if (comm_total != n_total || !comm_costs) comm_costs = dalloc(static_cast<size_t>(n_total));
+      comm_total = n_total;
+    }
+#else
+    (void)comm; (void)n_total; throw std::logic_error("no RCCL in the host emulation");
+#endif
+  }
+  // publish step of the Nash strategies (update_initial_with_best for coupled costs, nash.hpp:66-71): every rank receives every
+  // agent's trajectory and cost in the reference layout, [n_total][T+1][nx], [n_total][T][nu], [n_total].  The shard is written
+  // straight to its displacement in the caller's buffers (layout conversion on the device) and travels as one collective per array.
+  void all_gather_solution(void* comm_, int n_total, double* X_all, double* U_all, double* cost_all) override {
+#if !defined(MAS_HOST_EMULATION)
+    const Comm* c = static_cast<const Comm*>(comm_);
+    if (!c) throw std::invalid_argument("null communicator");
+    int lo = 0, hi = 0; shard_range(n_total, c->n_ranks, c->rank, &lo, &hi);
+    if (hi - lo != d.N) throw std::invalid_argument("this handle's agent count is not the shard size of its rank");
+    const size_t px = static_cast<size_t>(d.T + 1) * NX, pu = static_cast<size_t>(d.T) * NU;
+    if (X_all) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NX, X, X_all + lo * px, d.T + 1}, d.N, d.T + 1); c->all_gather_shards(X_all, n_total, px, be.cur); }
+    if (U_all) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, U, U_all + lo * pu, d.T}, d.N, d.T); c->all_gather_shards(U_all, n_total, pu, be.cur); }
+    if (cost_all) { be.d2d(cost_all + lo, cost, sizeof(double) * d.N); c->all_gather_shards(cost_all, n_total, 1, be.cur); }
+    be.sync();
+#else
+    (void)comm_; (void)n_total; (void)X_all; (void)U_all; (void)cost_all; throw std::logic_error("no RCCL in the host emulation");
+#endif
   }
 
   void run_centralized() override {                      // centralized.hpp:18-38, block-diagonal reading
@@ -441,8 +513,13 @@ class SolverImpl final : public SolverBase {
   }
 
   void get_solution(double* Xo, double* Uo, double* co, int32_t* it, int32_t* ex, bool device_ptr) override {
-    if (Xo) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NX, X, stage, d.T + 1}, d.N, d.T + 1); download(Xo, static_cast<size_t>(d.N) * (d.T + 1) * NX, device_ptr); }
-    if (Uo) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, U, stage, d.T}, d.N, d.T); download(Uo, static_cast<size_t>(d.N) * d.T * NU, device_ptr); }
+    if (device_ptr) {                  // the layout conversion writes the caller's device buffers directly
+      if (Xo) be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NX, X, Xo, d.T + 1}, d.N, d.T + 1);
+      if (Uo) be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, U, Uo, d.T}, d.N, d.T);
+    } else {
+      if (Xo) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NX, X, stage, d.T + 1}, d.N, d.T + 1); download(Xo, static_cast<size_t>(d.N) * (d.T + 1) * NX, false); }
+      if (Uo) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, U, stage, d.T}, d.N, d.T); download(Uo, static_cast<size_t>(d.N) * d.T * NU, false); }
+    }
     if (co) { if (device_ptr) be.d2d(co, cost, sizeof(double) * d.N); else be.d2h(co, cost, sizeof(double) * d.N); }
     if (it) be.d2h(it, iters_total, sizeof(int) * d.N);
     if (ex) be.d2h(ex, exit_code, sizeof(int) * d.N);
@@ -1038,6 +1115,11 @@ class SolverImpl final : public SolverBase {
   double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
+  JointState *joint = nullptr, *host_joint = nullptr;     // Nash line search decided on the device; its pinned read-back copy
+#if !defined(MAS_HOST_EMULATION)
+  Comm* comm_exchange = nullptr;                          // RCCL communicator of the sharded block list (owned by the caller)
+#endif
+  double* comm_costs = nullptr; int comm_total = 0;       // [comm_total] every rank's costs in global block order
   int *slot_of[2] = {nullptr, nullptr}, *fused_error = nullptr;   // fused rounds: every agent's position in live_lists[k]; raised when a bounded LDS wait gave up
   int *live_lists[2] = {nullptr, nullptr}, *live_count0 = nullptr;   // agents still active, compacted by select (round r reads list r & 1, writes the other); count of round 0 (= N)
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)

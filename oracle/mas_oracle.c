@@ -376,11 +376,47 @@ void mas_ilqr_set_params(mas_ilqr* s, int max_iterations, double tolerance, doub
   s->max_iterations = max_iterations; s->tolerance = tolerance; s->max_ms = max_ms; s->debug = debug;
 }
 
+/* ---- arithmetic variants (test infrastructure for the POPULATION tolerance) ----
+ * Two readings of Eigen this restatement cannot check against a real Eigen build:
+ *   sum order     0 = products summed in index order from 0.0 (the default: coefficient-based lazy product)
+ *                 1 = SSE2 packet-pairwise: even and odd terms summed separately, then added -- (a0b0+a2b2)+(a1b1+a3b3)
+ *   symmetrise    0 = the aliased in-place statement below (no temporary)
+ *                 1 = the mathematical mean 0.5 (V + V^T) of the OLD values (as if Eigen evaluated into a temporary)
+ * The parity tests always run variant (0, 0); tests/test_population_tolerance.py runs the others to bound what the unverifiable
+ * readings, the trig library and one-ulp input changes can move on the POPULATION level. */
+static int g_sum_order = 0, g_symmetrise = 0;
+void mas_oracle_set_arith_variant(int sum_order, int symmetrise) { g_sum_order = sum_order; g_symmetrise = symmetrise; }
+
+/* sum_k a[k*sa] * b[k*sb], k < p, in the order of the selected variant */
+static double dot_strided(const double* a, size_t sa, const double* b, size_t sb, int p) {
+  if (g_sum_order == 0 || p < 4) {
+    double s = 0.0;
+    for (int k = 0; k < p; ++k) s += a[(size_t)k * sa] * b[(size_t)k * sb];
+    return s;
+  }
+  double even = a[0] * b[0], odd = a[sa] * b[sb];
+  int k = 2;
+  for (; k + 1 < p; k += 2) { even += a[(size_t)k * sa] * b[(size_t)k * sb]; odd += a[(size_t)(k + 1) * sa] * b[(size_t)(k + 1) * sb]; }
+  double s = even + odd;
+  if (k < p) s += a[(size_t)k * sa] * b[(size_t)k * sb];
+  return s;
+}
+
 /* in-place  V = 0.5 * (V + V^T)  exactly as Eigen executes the reference's aliased
  * statement (ilqr.hpp:102,192): no temporary is made for a cwise expression, the
  * mixed storage orders force the scalar column-major traversal, so entry (i,j), i>j,
  * is averaged from the old values and entry (j,i) then sees the already-updated (i,j). */
 static void symmetrise_inplace(double* V, int n) {
+  if (g_symmetrise == 1) {                       /* variant: every entry from the old values */
+    for (int j = 0; j < n; ++j)
+      for (int i = j + 1; i < n; ++i) {
+        const double m = 0.5 * (V[(size_t)j * n + i] + V[(size_t)i * n + j]);
+        const double m2 = 0.5 * (V[(size_t)i * n + j] + V[(size_t)j * n + i]);
+        V[(size_t)j * n + i] = m; V[(size_t)i * n + j] = m2;
+      }
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 0.5 * (V[(size_t)i * n + i] + V[(size_t)i * n + i]);
+    return;
+  }
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < n; ++i)
       V[(size_t)j * n + i] = 0.5 * (V[(size_t)j * n + i] + V[(size_t)i * n + j]);
@@ -428,20 +464,12 @@ static void llt_solve_identity(const double* L, int n, double* Inv) {
 /* C(m x n) = A^T(m x p from A: p x m) * B(p x n) */
 static void mat_AtB(const double* A, int p, int m, const double* B, int n, double* C) {
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < m; ++i) {
-      double s = 0.0;
-      for (int k = 0; k < p; ++k) s += A[(size_t)i * p + k] * B[(size_t)j * p + k];
-      C[(size_t)j * m + i] = s;
-    }
+    for (int i = 0; i < m; ++i) C[(size_t)j * m + i] = dot_strided(A + (size_t)i * p, 1, B + (size_t)j * p, 1, p);
 }
 /* C(m x n) = A(m x p) * B(p x n) */
 static void mat_AB(const double* A, int m, int p, const double* B, int n, double* C) {
   for (int j = 0; j < n; ++j)
-    for (int i = 0; i < m; ++i) {
-      double s = 0.0;
-      for (int k = 0; k < p; ++k) s += A[(size_t)k * m + i] * B[(size_t)j * p + k];
-      C[(size_t)j * m + i] = s;
-    }
+    for (int i = 0; i < m; ++i) C[(size_t)j * m + i] = dot_strided(A + i, (size_t)m, B + (size_t)j * p, 1, p);
 }
 
 typedef struct {

@@ -33,6 +33,9 @@
 extern "C" {
 #endif
 
+/* arithmetic variants of the restatement (population-tolerance tests only; parity always uses (0, 0)): see mas_oracle.c */
+void mas_oracle_set_arith_variant(int sum_order /* 0 index order, 1 packet-pairwise */, int symmetrise /* 0 aliased, 1 mean of old values */);
+
 /* ------------------------------------------------------------------ OCP -- */
 /* Mirrors struct OCP, include/multi_agent_solver/ocp.hpp:30-100.            */
 struct mas_ocp;

@@ -59,6 +59,7 @@ def lib() -> C.CDLL:
         _lib.mas_model_default_params.argtypes = [C.c_int, C.c_int, d]
         _lib.mas_oracle_max_threads.restype = C.c_int
         _lib.mas_oracle_set_trig_mode.argtypes = [C.c_int]
+        _lib.mas_oracle_set_arith_variant.argtypes = [C.c_int, C.c_int]
         _lib.mas_oracle_get_trig_mode.restype = C.c_int
         _lib.mas_oracle_set_al_params.argtypes = [C.c_double] * 4
         _lib.mas_oracle_set_exit_buffer.argtypes = [i]
@@ -98,6 +99,12 @@ def set_trig_mode(mode: str) -> None:
     """'libm': platform sin/cos/tan, as a glibc-linked reference binary calls them (default).
     'det': include/mas_dettrig.h, the bit-reproducible implementation the HIP path uses."""
     lib().mas_oracle_set_trig_mode({"libm": 0, "det": 1}[mode])
+
+
+def set_arith_variant(sum_order: str = "index", symmetrise: str = "aliased") -> None:
+    """readings of Eigen the restatement cannot check (mas_oracle.c): products summed in index order or SSE2-packet-pairwise;
+    V = 0.5 (V + V^T) aliased in place or as the mean of the old values.  Parity tests use the defaults."""
+    lib().mas_oracle_set_arith_variant({"index": 0, "pairwise": 1}[sum_order], {"aliased": 0, "mean": 1}[symmetrise])
 
 
 def get_trig_mode() -> str:

@@ -38,14 +38,24 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert p["vs_det_oracle"] == "exact" and p["compared_agents"] == 512
     assert set(p["vs_libm_oracle"]) >= {"median_rel", "max_rel", "total_rel", "frac_le_1e-5", "north_star_tolerance_1e-5_met"}
     assert j["also_config2"]["parity"]["vs_det_oracle"] == "exact"
-    assert r_has_both_fracs(j["roofline"])
+    # round 3: the four-state models run two-kernel rounds; the roofline kernel is the fused linearise + Riccati kernel (sweep +
+    # backward bytes of SURVEY 8(d)), and the sweep as a kernel of its own is measured in the same run with the five-kernel round
+    r = j["roofline"]
+    assert r["kernel"] == "mas_linearise_riccati_kernel" and r["algorithmic_bytes_per_agent"] == 51392 + 54432
+    u = j["unfused_round"]
+    assert u["ms_per_step"] > 0 and u["speedup_of_the_fused_round"] > 0.9 and r_has_both_fracs(u["roofline_sweep"])
+    assert "traffic" in r and "traffic_source" in r          # a number only with counters collected from these very sources, else null + reason
+    pt = p["population_tolerance"]
+    assert pt["met"] is True and pt["agents"] == 512 and set(pt["worst_over_variants"]) == set(pt["bounds"])
+    cb = j["cpu_baseline"]
+    assert cb["repeats"] >= 3 and cb["min"] <= cb["value"] <= cb["max"]
 
 
 def r_has_both_fracs(r):
-    return "inkernel_span" in r and 0.0 < r["inkernel_span"]["frac"] < 1.0 and r["algorithmic_bytes_per_agent"] == 51392
+    return r["kernel"] == "mas_sweep_kernel" and "inkernel_span" in r and 0.0 < r["inkernel_span"]["frac"] < 1.0 and r["algorithmic_bytes_per_agent"] == 51392
 
 
-@pytest.mark.parametrize("workload,agents,bytes_per_agent", [("c4", 256, 38592), ("c5", 128, 185984)])
+@pytest.mark.parametrize("workload,agents,bytes_per_agent", [("c4", 256, 38592 + 8 * 50 * 88 + 32 + 8 * 50 * 20), ("c5", 128, 185984)])
 def test_config4_and_config5_are_bench_workloads(workload, agents, bytes_per_agent):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
                           "--agents-per-gpu", str(agents)], capture_output=True, text=True, timeout=900, cwd=ROOT)

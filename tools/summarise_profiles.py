@@ -17,7 +17,7 @@ W, TAG, D = sys.argv[1], sys.argv[2], sys.argv[3]
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
 
-KERNELS = (("sweep", ("mas_sweep_kernel", "SweepBody")), ("central_backward", ()),
+KERNELS = (("linearise_riccati", ("mas_linearise_riccati_kernel",)), ("sweep", ("mas_sweep_kernel", "SweepBody")), ("central_backward", ()),
            ("backward", ("mas_backward_tile_kernel", "mas_backward_row_kernel", "BackwardBody")), ("forward", ("ForwardBody",)), ("select", ("SelectBody",)),
            ("commit", ("CommitBody", "CommitSlotBody")), ("trust_reroll", ("TrustRerollBody",)), ("trust_norm", ("TrustNormBody",)), ("trust_copy", ("TrustCopyBody",)),
            ("trust_region", ("TrustRegion",)), ("rollout_cost", ("RolloutCostBody",)))
@@ -71,7 +71,10 @@ def counters(csv_path):
     return tot, n, first, ns
 
 
-meta = {"workload": W, "commit": commit_id(), "collected_by": "tools/collect_profiles.sh " + W + " " + TAG}
+sys.path.insert(0, ROOT)
+from multi_agent_solver_amd.source_hash import source_hash  # noqa: E402
+
+meta = {"workload": W, "commit": commit_id(), "source_hash": source_hash(), "collected_by": "tools/collect_profiles.sh " + W + " " + TAG}
 alg = json.load(open(os.path.join(D, "algorithmic.json")))
 
 # ---- 1. kernel stats of the bench run
@@ -83,19 +86,23 @@ if os.path.exists(bj):
     lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
     if lines:
         j = json.loads(lines[-1])
-        j["_note"] = "bench.py run UNDER rocprofv3 --kernel-trace --stats (profiler overhead included in `value`); its roofline.avg_launch_us is the HIP-event average to hold against AverageNs of mas_sweep_kernel in the kernel_stats.csv of the same run"
+        r = j.get("roofline") or {}
+        kname = r.get("kernel", "mas_sweep_kernel")
+        j["_note"] = ("bench.py run UNDER rocprofv3 --kernel-trace --stats (profiler overhead included in `value`); its roofline.avg_launch_us is the HIP-event average to hold "
+                      "against AverageNs of " + kname + " in the kernel_stats.csv of the same run")
+        j["source_hash"] = meta["source_hash"]
         if stats:
             with open(stats) as f:
                 for row in csv.DictReader(f):
-                    if "mas_sweep_kernel" in row["Name"]:
-                        j["_rocprof_sweep"] = {"calls": int(row["Calls"]), "average_us": float(row["AverageNs"]) / 1e3, "total_ms": float(row["TotalDurationNs"]) / 1e6}
-                        r = j.get("roofline") or {}
+                    if kname in row["Name"]:
+                        j["_rocprof_roofline_kernel"] = {"kernel": kname, "calls": int(row["Calls"]), "average_us": float(row["AverageNs"]) / 1e3, "total_ms": float(row["TotalDurationNs"]) / 1e6}
                         if r.get("algorithmic_bytes_per_launch") and r.get("launches"):
                             # bench's instrumented pass and the whole profiled process share the same kernels; rocprof averages over
                             # warm-up, timed and instrumented passes alike, so compare average durations, not totals
                             a = r["algorithmic_bytes_per_launch"] / (float(row["AverageNs"]) * 1e-9) / 1e9
-                            j["_rocprof_sweep"]["achieved_GBs_at_rocprof_average"] = a
-                            j["_rocprof_sweep"]["frac_at_rocprof_average"] = a / 8000.0
+                            j["_rocprof_roofline_kernel"]["achieved_GBs_at_rocprof_average"] = a
+                            j["_rocprof_roofline_kernel"]["frac_at_rocprof_average"] = a / 8000.0
+                        break
         json.dump(j, open(os.path.join(PROF, f"{TAG}_bench_{W}_under_rocprof.json"), "w"), indent=1)
 
 # ---- 2. HBM traffic
