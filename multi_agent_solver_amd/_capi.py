@@ -64,7 +64,9 @@ class MasHipError(RuntimeError):
 def _preload_torch_hip_runtime() -> None:
     """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes
     in one process cannot both initialise the GPU, so when torch is installed its copy is loaded first
-    (RTLD_GLOBAL, without importing torch) and libmas_hip.so then binds to it by SONAME."""
+    (RTLD_GLOBAL, without importing torch) and libmas_hip.so then binds to it by SONAME.  The same holds for
+    librccl.so.1, which libmas_hip.so opens on first use of its mas_hip_comm_* entry points: torch's copy first, so that the
+    library and a later `import torch` share ONE RCCL built against that one HIP runtime."""
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -72,9 +74,18 @@ def _preload_torch_hip_runtime() -> None:
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    # libamdhip64 globally (libmas_hip.so binds its HIP symbols to it); librccl LOCALLY: it only has to be the instance a later
+    # dlopen("librccl.so.1") finds by SONAME -- with its symbols in the global scope, a process that also holds torch and an OpenMP
+    # library aborted at exit (double free)
+    for name, mode in (("libamdhip64.so", C.RTLD_GLOBAL), ("librccl.so", C.RTLD_LOCAL)):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=mode)
+            except OSError:
+                if name == "libamdhip64.so":
+                    raise
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

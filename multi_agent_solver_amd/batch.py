@@ -28,6 +28,47 @@ def _dp(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+class Comm:
+    """RCCL communicator made by the library (include/mas_hip.h: mas_hip_comm_*), one per rank / GPU.  `unique_id()` on one rank,
+    the 128 bytes to the others by any channel (torch.distributed broadcast, a file, MPI), then `Comm(id, n_ranks, rank, device)`
+    on every rank (collective)."""
+
+    def __init__(self, unique_id: bytes, n_ranks: int, rank: int, device: int = 0, lib=None):
+        self._lib = lib or _capi.product_lib()
+        self.n_ranks, self.rank, self.device = n_ranks, rank, device
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        h = C.c_void_p()
+        rc = self._lib.mas_hip_comm_create(C.cast(buf, C.c_void_p), n_ranks, rank, device, C.byref(h))
+        if rc != _capi.OK:
+            raise _capi.MasHipError(rc, (self._lib.mas_hip_comm_last_error() or b"").decode())
+        self._h = h
+
+    @staticmethod
+    def unique_id(lib=None) -> bytes:
+        lib = lib or _capi.product_lib()
+        buf = C.create_string_buffer(128)
+        rc = lib.mas_hip_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != _capi.OK:
+            raise _capi.MasHipError(rc, (lib.mas_hip_comm_last_error() or b"").decode())
+        return buf.raw
+
+    def shard_range(self, n_total: int, rank: int = None):
+        lo, hi = C.c_int(), C.c_int()
+        self._lib.mas_hip_shard_range(n_total, self.n_ranks, self.rank if rank is None else rank, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def close(self):
+        if self._h:
+            self._lib.mas_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class BatchSolver:
     def __init__(self, model_id: int, n_agents: int, horizon_steps: int, dt: float, params=None,
                  input_bounds=None, no_input_bounds: bool = False, device: int = 0, stream: int = 0, lib=None):
@@ -83,6 +124,16 @@ class BatchSolver:
         if rc != _capi.OK:
             msg = self._lib.mas_hip_last_error(self._h)
             raise _capi.MasHipError(rc, msg.decode() if msg else "")
+
+    # -- agents sharded over GPUs: RCCL inside the library (include/mas_hip.h) ---------------
+    def all_gather_solution_device(self, comm: "Comm", n_total: int, X_all_ptr: int, U_all_ptr: int, cost_all_ptr: int):
+        """every rank receives every agent's trajectory: DEVICE buffers [n_total][T+1][nx], [n_total][T][nu], [n_total] (0 = skip)"""
+        self._check(self._lib.mas_hip_all_gather_solution(self._h, comm._h, n_total, C.c_void_p(X_all_ptr or None), C.c_void_p(U_all_ptr or None),
+                                                          C.c_void_p(cost_all_ptr or None)))
+
+    def set_comm_cost_exchange(self, comm, n_total: int = 0):
+        """line-search strategy: total cost over all ranks' agents formed on the device (None: local sum)"""
+        self._check(self._lib.mas_hip_set_comm_cost_exchange(self._h, comm._h if comm is not None else None, n_total))
 
     def set_option(self, key: str, value: int):
         """choose between bit-identical kernel forms (include/mas_hip.h: mas_hip_set_option); results never depend on it"""

@@ -10,7 +10,11 @@
 
 #include "mas_solver.hpp"
 
+#if !defined(MAS_HOST_EMULATION)
 struct mas_hip_comm { mas::Comm c; };
+#else
+struct mas_hip_comm { int unused; };
+#endif
 
 struct mas_hip_solver {
   std::unique_ptr<mas::SolverBase> impl;
@@ -68,6 +72,7 @@ int create_impl(const mas_hip_problem_desc* desc, void* stream, mas_hip_solver**
   }
 }
 thread_local std::string g_comm_error;
+#if !defined(MAS_HOST_EMULATION)
 template <class Fn>
 int comm_guarded(Fn&& fn) {
   try {
@@ -78,6 +83,7 @@ int comm_guarded(Fn&& fn) {
   } catch (const std::invalid_argument& e) { g_comm_error = e.what(); return MAS_HIP_ERR_INVALID;
   } catch (const std::exception& e) { g_comm_error = e.what(); return MAS_HIP_ERR_RUNTIME; }
 }
+#endif
 }  // namespace
 
 extern "C" {
@@ -147,6 +153,7 @@ int mas_hip_total_cost(mas_hip_solver* h, double* total) {
 int mas_hip_set_cost_exchange(mas_hip_solver* h, mas_hip_cost_exchange_fn fn, void* ctx) {
   return guarded(h, [&](mas::SolverBase& s) { s.cost_exchange = fn; s.cost_exchange_ctx = ctx; });
 }
+#if !defined(MAS_HOST_EMULATION)
 // ---- RCCL communicators (mas_rccl.hpp) ----
 const char* mas_hip_comm_last_error(void) { return g_comm_error.c_str(); }
 int mas_hip_comm_unique_id(void* id_out) {
@@ -207,6 +214,21 @@ int mas_hip_all_gather_solution(mas_hip_solver* h, mas_hip_comm* c, int n_total,
 int mas_hip_set_comm_cost_exchange(mas_hip_solver* h, mas_hip_comm* c, int n_total) {
   return guarded(h, [&](mas::SolverBase& s) { s.set_comm_exchange(c ? &c->c : nullptr, n_total); });
 }
+#else   // host emulation (tests/hostcheck): no devices, no RCCL
+const char* mas_hip_comm_last_error(void) { return "no RCCL in the host emulation"; }
+int mas_hip_comm_unique_id(void*) { return MAS_HIP_ERR_RUNTIME; }
+int mas_hip_comm_create(const void*, int, int, int, mas_hip_comm**) { return MAS_HIP_ERR_RUNTIME; }
+int mas_hip_comm_create_all(int, const int*, mas_hip_comm**) { return MAS_HIP_ERR_RUNTIME; }
+int mas_hip_comm_destroy(mas_hip_comm*) { return MAS_HIP_ERR_RUNTIME; }
+void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi) {
+  const int base = n_ranks > 0 ? n_total / n_ranks : 0, extra = n_ranks > 0 ? n_total % n_ranks : 0;
+  const int a = rank * base + (rank < extra ? rank : extra);
+  if (lo) *lo = a;
+  if (hi) *hi = a + base + (rank < extra ? 1 : 0);
+}
+int mas_hip_all_gather_solution(mas_hip_solver*, mas_hip_comm*, int, void*, void*, void*) { return MAS_HIP_ERR_RUNTIME; }
+int mas_hip_set_comm_cost_exchange(mas_hip_solver*, mas_hip_comm*, int) { return MAS_HIP_ERR_RUNTIME; }
+#endif
 int mas_hip_get_trust_radii_host(mas_hip_solver* h, double* radii) {
   if (!radii) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) { s.get_trust_radii(radii); });

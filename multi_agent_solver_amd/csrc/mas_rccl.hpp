@@ -47,7 +47,7 @@ struct RcclApi {
  private:
   void load() {
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);       // (local: its symbols are reached through dlsym only)
       if (handle) break;
     }
     if (!handle) { error = std::string("librccl.so.1 could not be opened: ") + dlerror(); return; }
@@ -86,7 +86,6 @@ struct Comm {
   // rank inside a group -- by displacement, nothing is padded.
   void all_gather_shards(double* all, int n_total, size_t per_agent, hipStream_t stream) const {
     const RcclApi& api = RcclApi::get();
-    if (n_ranks == 1) return;
     int lo = 0, hi = 0;
     if (n_total % n_ranks == 0) {
       shard_range(n_total, n_ranks, rank, &lo, &hi);

@@ -26,6 +26,9 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <variant>
 #include <vector>
 
@@ -323,12 +326,12 @@ inline std::vector<std::vector<int>> group_blocks(const MultiAgentProblem& p) {
   return groups;
 }
 
-inline BatchedProblem upload(MultiAgentProblem& problem, const std::vector<int>& members, const SolverParams& params, bool warm_from_best) {
+inline BatchedProblem upload(MultiAgentProblem& problem, const std::vector<int>& members, const SolverParams& params, bool warm_from_best, int device = 0) {
   const OCP& f = *problem.blocks[members.front()].agent->ocp;
   BatchedProblem bp;
   bp.members = members;
   bp.N = static_cast<int>(members.size()); bp.T = f.horizon_steps; bp.nx = f.state_dim; bp.nu = f.control_dim;
-  bp.batch = std::make_unique<Batch>(f.model, bp.N, bp.T, f.dt, f.input_lower_bounds, f.input_upper_bounds);
+  bp.batch = std::make_unique<Batch>(f.model, bp.N, bp.T, f.dt, f.input_lower_bounds, f.input_upper_bounds, device);
   bp.batch->set_params(params);
   std::vector<double> x0(static_cast<size_t>(bp.N) * bp.nx), U(static_cast<size_t>(bp.N) * bp.T * bp.nu, 0.0);
   for (int i = 0; i < bp.N; ++i) {
@@ -388,16 +391,102 @@ inline Solution download(MultiAgentProblem& problem, BatchedProblem& bp, bool pu
   return sol;
 }
 
+// ---- several GPUs in one process: the device plan ----
+// The reference fans the agents out over OpenMP threads (nash.hpp:59-71); here the id-sorted block list is cut into contiguous
+// ranges (mas_hip_shard_range), one per entry of the device plan, and every range is driven by its own host thread on its own
+// handle.  Default plan: every visible device.  set_device_plan({0, 0}) puts two shards on one GPU (tests on a one-GPU box);
+// environment MAS_AMD_DEVICES="0,1,2,3" overrides the default.
+inline std::vector<int>& device_plan_storage() { static std::vector<int> plan; return plan; }
+inline void set_device_plan(std::vector<int> devices) { device_plan_storage() = std::move(devices); }
+inline std::vector<int> device_plan() {
+  if (!device_plan_storage().empty()) return device_plan_storage();
+  std::vector<int> plan;
+  if (const char* e = std::getenv("MAS_AMD_DEVICES")) {
+    for (const char* c = e; *c;) { char* end = nullptr; const long v = std::strtol(c, &end, 10); if (end == c) break; plan.push_back(static_cast<int>(v)); c = (*end == ',') ? end + 1 : end; }
+  }
+  if (plan.empty()) { const int n = std::max(1, mas_hip_device_count()); for (int i = 0; i < n; ++i) plan.push_back(i); }
+  return plan;
+}
+// shards smaller than this stay on one device (a handle per device costs ~1 ms to set up)
+constexpr int kMinAgentsPerShard = 32;
+
+// total cost over the shards of one process when two of them share a device (RCCL refuses two ranks on one GPU): the host-callback
+// exchange of include/mas_hip.h -- every shard deposits its costs at its displacement, all meet at a barrier, each forms the sum in
+// global block order
+struct HostExchange {
+  std::vector<double> all; std::vector<int> lo; int parties = 0;
+  std::mutex m; std::condition_variable cv; int arrived = 0; long generation = 0;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const long g = generation;
+    if (++arrived == parties) { arrived = 0; ++generation; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != g; });
+  }
+  struct Party { HostExchange* ex; int rank; };
+  static int callback(void* ctx, const double* costs, int32_t n, double* total) {
+    auto* p = static_cast<Party*>(ctx);
+    std::copy(costs, costs + n, p->ex->all.begin() + p->ex->lo[p->rank]);
+    p->ex->barrier();
+    double s = 0.0; for (double v : p->ex->all) s += v;      // detail::compute_total_cost: c += cost, in block order
+    *total = s;
+    p->ex->barrier();                                         // nobody overwrites `all` before everybody has summed it
+    return 0;
+  }
+};
+
+// run `run(batch)` on the members of one homogeneous group, sharded over the device plan; `coupled`: the shards exchange the total
+// cost of all agents (line search) -- over RCCL inside the library when every shard has its own device, through HostExchange otherwise
+template <class Run>
+inline void run_sharded(MultiAgentProblem& problem, const std::vector<int>& members, const SolverParams& params, bool publish_initial,
+                        std::vector<int>& iterations, bool coupled, Run&& run) {
+  std::vector<int> plan = device_plan();
+  int shards = static_cast<int>(plan.size());
+  while (shards > 1 && static_cast<int>(members.size()) / shards < kMinAgentsPerShard) --shards;
+  if (shards <= 1) {
+    auto bp = upload(problem, members, params, true, plan.empty() ? 0 : plan[0]);
+    run(*bp.batch);
+    download_into(problem, bp, publish_initial, iterations);
+    return;
+  }
+  plan.resize(shards);
+  const int n_total = static_cast<int>(members.size());
+  bool distinct = true;
+  for (int i = 0; i < shards; ++i) for (int j = i + 1; j < shards; ++j) if (plan[i] == plan[j]) distinct = false;
+  std::vector<mas_hip_comm*> comms(shards, nullptr);
+  HostExchange host; std::vector<HostExchange::Party> parties(shards);
+  if (coupled) {
+    if (distinct) { if (mas_hip_comm_create_all(shards, plan.data(), comms.data()) != MAS_HIP_OK) throw HipError(MAS_HIP_ERR_RUNTIME, std::string("mas_hip_comm_create_all: ") + mas_hip_comm_last_error()); }
+    else { host.all.assign(n_total, 0.0); host.lo.resize(shards); host.parties = shards; }
+  }
+  std::vector<std::exception_ptr> errors(shards);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < shards; ++r) {
+    int lo = 0, hi = 0; mas_hip_shard_range(n_total, shards, r, &lo, &hi);
+    if (coupled && !distinct) { host.lo[r] = lo; parties[r] = {&host, r}; }
+    threads.emplace_back([&, r, lo, hi] {
+      try {
+        const std::vector<int> mine(members.begin() + lo, members.begin() + hi);
+        auto bp = upload(problem, mine, params, true, plan[r]);
+        if (coupled) {
+          if (distinct) bp.batch->check(mas_hip_set_comm_cost_exchange(bp.batch->get(), comms[r], n_total), "set_comm_cost_exchange");
+          else bp.batch->check(mas_hip_set_cost_exchange(bp.batch->get(), &HostExchange::callback, &parties[r]), "set_cost_exchange");
+        }
+        run(*bp.batch);
+        download_into(problem, bp, publish_initial, iterations);     // every shard writes its own OCPs and its own entries of `iterations`
+      } catch (...) { errors[r] = std::current_exception(); }
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (auto* c : comms) if (c) mas_hip_comm_destroy(c);
+  for (auto& e : errors) if (e) std::rethrow_exception(e);
+}
+
 // per-agent strategies over a possibly mixed agent list: one batch per homogeneous group
 template <class Run>
 inline Solution run_grouped(MultiAgentProblem& problem, const SolverParams& params, Run&& run) {
   if (problem.blocks.empty()) return Solution{};      // nothing to solve: empty Solution, total_cost 0 (nash.hpp:23-37)
   std::vector<int> iterations(problem.blocks.size(), 0);
-  for (const auto& members : group_blocks(problem)) {
-    auto bp = upload(problem, members, params, true);
-    run(*bp.batch);
-    download_into(problem, bp, true, iterations);
-  }
+  for (const auto& members : group_blocks(problem)) run_sharded(problem, members, params, true, iterations, /*coupled=*/false, run);
   return collect_solution(problem, iterations);
 }
 
@@ -463,9 +552,13 @@ struct LineSearchNashStrategy {                    // strategies/nash.hpp:270-28
   Solution operator()(MultiAgentProblem& problem) {
     problem.compute_offsets();
     if (problem.blocks.empty()) return Solution{};
-    auto bp = detail::upload(problem, params, true);
-    bp.batch->check(mas_hip_run_line_search(bp.batch->get(), max_outer), "run_line_search");
-    return detail::download(problem, bp, true);
+    detail::require_homogeneous(problem);
+    std::vector<int> all(problem.blocks.size()), iterations(problem.blocks.size(), 0);
+    for (size_t i = 0; i < all.size(); ++i) all[i] = static_cast<int>(i);
+    const int outer = max_outer;
+    detail::run_sharded(problem, all, params, true, iterations, /*coupled=*/true,
+                        [outer](detail::Batch& b) { b.check(mas_hip_run_line_search(b.get(), outer), "run_line_search"); });
+    return detail::collect_solution(problem, iterations);
   }
 };
 

@@ -166,3 +166,18 @@ def test_repeated_solves_reuse_the_device_handle(exe_dir):
     assert fa["cost"] == fb["cost"] and fa["iterations_last_call"] == fb["iterations_last_call"] == "1"      # counts restart with every new problem
     assert float(fa["ms_per_call"]) < float(fb["ms_per_call"])
     print("cached", fa["ms_per_call"], "ms/call; create-per-call", fb["ms_per_call"], "ms/call")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", ["sequential", "trustregion", "linesearch"])
+def test_block_list_sharded_over_the_device_plan_in_one_process(exe_dir, strategy):
+    """mas_amd::MultiAgentProblem strategies shard the id-sorted block list over the device plan, one handle + host thread per entry
+    (replaces the OpenMP fan-out of nash.hpp:59-71).  On a one-GPU box the plan "0,0,0" puts three shards (uneven: 100 agents) on the
+    same device; line search then forms the total cost of all agents through the in-process exchange.  Same bits as one handle."""
+    args = ("--agents", "100", "--strategy", strategy, "--horizon", "30", "--max-outer", "3")
+    one = subprocess.run([os.path.join(exe_dir, "multi_agent_single_track"), *args], capture_output=True, text=True, timeout=600, env=dict(os.environ, MAS_AMD_DEVICES="0"))
+    three = subprocess.run([os.path.join(exe_dir, "multi_agent_single_track"), *args], capture_output=True, text=True, timeout=600, env=dict(os.environ, MAS_AMD_DEVICES="0,0,0"))
+    assert one.returncode == 0 and three.returncode == 0, (one.stderr, three.stderr)
+    strip = lambda out: "\n".join([re.sub(r" time_ms=\S+", "", out.splitlines()[0])] + out.splitlines()[1:])      # noqa: E731
+    assert strip(one.stdout) == strip(three.stdout)                     # result line and every agent's trajectory table
+    assert _result_line(one.stdout).group(3) == "100"
