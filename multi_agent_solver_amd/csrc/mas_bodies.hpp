@@ -51,11 +51,7 @@ MAS_HD void st_off(double* base, unsigned byte_off, double v) { *reinterpret_cas
 constexpr int kTileChunk = 16;
 // lanes that share one agent's backward recursion (mas_backward_tile_kernel): 16 or 32; 64 / this = agents per wavefront
 constexpr int kBackwardLanesPerAgent = 16;   // measured on C3: 16 -> 145 us per launch, 32 -> 165 us
-#if defined(MAS_BWD_WPB)
-constexpr int kBackwardWavesPerBlock = MAS_BWD_WPB;   // (A/B builds)
-#else
-constexpr int kBackwardWavesPerBlock = 4;    // per-agent backward pass: wavefronts per workgroup (placement: one per SIMD of a CU)
-#endif
+constexpr int kBackwardWavesPerBlock = 4;    // per-agent backward pass: wavefronts per workgroup (placement: one per SIMD of a CU; measured 1 / 2 / 8: 6.51 / 7.63 / 7.69 against 6.11 ms per C3 run)
 constexpr int kForwardTrialsPerBlock = 1;    // line-search rollouts: alpha trials (wavefronts) per workgroup.  Measured on C3 (us per launch, full rounds): 1 -> 125, 2 -> 190 (two workgroups double up on the same SIMDs of a CU), 4 -> 140 (four issue-bound wavefronts share a CU's front end while 96 CUs idle), 3 -> 128
 // centralised backward pass: wavefronts per workgroup.  Measured on C2 (256 agents, us per launch): 1 -> 416, 4 -> 293, 8 -> 330,
 // 16 -> 485: fewer arrivals per agreement against more wavefronts sharing a SIMD

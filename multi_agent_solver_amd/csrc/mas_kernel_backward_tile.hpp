@@ -1,0 +1,390 @@
+// mas_kernel_backward_tile.hpp -- backward Riccati recursion for any NX over an LDS tile per agent (HIP build only; see mas_kernels_hip.hpp)
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+#include "mas_kernel_backward_common.hpp"
+
+namespace mas {
+
+// ---------------------------------------------------------------- backward, 16 lanes/agent --
+template <class M>
+struct BackwardTileLayout {
+  using L = DerivLayout<M>;
+  static constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
+  // LDS tile of one agent, in doubles.  Two rules shape it (MI355X_MICROARCH.md, LDS): a ds_write_b64 is served in four
+  // groups of 16 consecutive lanes -- one agent's 16 lanes -- over 32 dword banks, so the 16 lanes must hit 16 different
+  // doubles modulo 16; and lanes that have nothing to write must NOT share one dummy address (sixteen lanes on one
+  // address cost fifteen extra cycles: that, not the operand reads, was the 64 conflict cycles per time step of round 1).
+  // Hence a PAD region of 16 doubles at an offset that is a multiple of 16: an idle lane writes pad_at(x) where x is the
+  // address it would have had if the item list went on -- the residues modulo 16 of one instruction stay a permutation.
+  static constexpr int oD = 0, oV = oD + ND, oVx = oV + NX * NX, oAtV = oVx + NX, oBtV = oAtV + NX * NX, oQx = oBtV + NU * NX,
+                       oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oL = oQuu + NU * NU, oNegZero = oL + NU * NU,
+                       kUsed = oNegZero + 1, oPad = (kUsed + 15) / 16 * 16, kEnd = oPad + 16;
+  // agents of one 32-lane read group (two tiles) kStrideMod doubles apart modulo 32
+  static constexpr int kStrideMod = 16;       // measured in round 2 (conflict cycles per wavefront for strides = 16 / 10 / 2 / 0 mod 32: 3,843 / 4,117 / 5,215 / 7,411; launch time within 1 %)
+  static constexpr int STRIDE = kEnd + ((kStrideMod - kEnd % 32) % 32 + 32) % 32;
+  static_assert(STRIDE >= kEnd, "tile stride");
+  __host__ __device__ static constexpr int pad_at(int x) { return oPad + (x & 15); }
+};
+
+// WPB = wavefronts per workgroup; the wavefronts of a workgroup are independent (each owns its four LDS tiles) except in the
+// shared ladder.  Two reasons for WPB = 4:
+//  * placement (per-agent Nash path): a workgroup's four wavefronts go to the four SIMDs of one CU, so 4096 agents = 256
+//    workgroups = exactly one wavefront per SIMD.  As 1024 single-wavefront workgroups the dispatcher doubles some SIMDs up
+//    while others stay empty, and the launch takes as long as its slowest SIMD: measured 163 us against 124 us per launch.
+//  * the shared ladder of the centralised strategy: the rung masks of a workgroup's wavefronts are first combined through
+//    LDS (one s_barrier), and only ONE wavefront per workgroup takes part in the cross-workgroup agreement, so 256 agents
+//    are 16 arrivals per time step instead of 64 -- and a problem that fits one workgroup needs no global agreement at all.
+template <class M, int LPA, bool SharedLadder = false, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ D,
+                                                               double* __restrict__ kff, double* __restrict__ Kfb,
+                                                               long long* __restrict__ reg_events, const int* __restrict__ active, int lo, int n,
+                                                               LadderSync sync) {
+  using TL = BackwardTileLayout<M>;
+  using L = DerivLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
+  constexpr int APW = 64 / LPA;                     // agents per wavefront (LPA lanes per agent)
+  constexpr int LL = 16;                            // ladder width: rungs tried at once (lanes beyond LL repeat rung lane % LL)
+  static_assert(LPA >= LL && 64 % LPA == 0, "lanes per agent");
+  // kLocalQuu (experiment, off): every lane forms q_uu itself right after pass 1, so that the LLT / ladder chain starts one
+  // LDS round trip earlier and pass 2 runs in its shadow.  Measured on C3: 142 us per launch against 132 us -- the 36 extra
+  // FP64 instructions per lane cost more than the round trip saves; the kernel is bound by dependent-issue latency
+  // (7 cycles per dependent FP64 instruction, ~255 of them per step), not by LDS.
+  constexpr bool kLocalQuu = false;
+  __shared__ double lds[WPB * APW * TL::STRIDE];
+  __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];   // rung masks of the workgroup's wavefronts, double-buffered by agreement parity
+  __shared__ unsigned blk_agreed[2];
+  unsigned agreement_parity = 0;
+
+  const int wave = static_cast<int>(threadIdx.x) >> 6;    // 0 when WPB == 1
+  const int tid = static_cast<int>(threadIdx.x) & 63, lane = tid & (LPA - 1), slot = tid / LPA, rung_lane = lane & (LL - 1);
+  const int slot0 = (static_cast<int>(blockIdx.x) * WPB + wave) * APW;
+  int a = lo + slot0 + slot;
+  bool valid, counted;
+  if (!SharedLadder && sync.live_list != nullptr) {
+    const int n_live = *sync.live_count;                    // uniform
+    if (slot0 >= n_live) return;
+    counted = slot0 + slot < n_live;
+    a = sync.live_list[counted ? slot0 + slot : slot0];     // a surplus slot of the last wavefront repeats its first agent: same values to the same addresses
+    valid = true;
+  } else {
+    valid = (a < n) && active[a] != 0;
+    counted = valid;
+  }
+  if (!SharedLadder && __ballot(valid) == 0ull) return;   // uniform for the (single-wave) block; a shared ladder needs every wavefront
+  if (SharedLadder && active[lo] == 0) return;             // the stacked solve has ended (all flags fall together): uniform over the whole launch
+  const int tile = wave * APW + slot;
+  double* T = lds + tile * TL::STRIDE;
+  // the tiles of a wavefront are private to it: what separates its LDS writes from its own later reads is the order in which
+  // one wavefront's LDS instructions execute, not a workgroup barrier (with one wavefront per workgroup __syncthreads()
+  // compiles to exactly that wait; with several it would be a real s_barrier nobody needs here)
+  auto wave_sync = [] {
+    if constexpr (WPB == 1) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  if (!valid) {                                     // idle slot: finite operands (its lanes run the same code, results unused)
+    for (int e = lane; e < TL::STRIDE; e += LPA) T[e] = 0.0;
+  }
+  if (lane == 0) T[TL::oNegZero] = -0.0;            // additive identity that keeps every bit of the other operand (x + -0.0 == x)
+  if (valid && lane == 0) {                         // terminal boundary condition, ilqr.hpp:92-102
+    double xT[NX], vx[NX], vxx[NX * NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = MAS_AT(X, d.T * NX + i, a);
+    terminal_boundary<M>(xT, vx, vxx, P);
+    MAS_UNROLL for (int i = 0; i < NX; ++i) T[TL::oVx + i] = vx[i];
+    MAS_UNROLL for (int i = 0; i < NX * NX; ++i) T[TL::oV + i] = vxx[i];
+  }
+
+  // ---- loop-invariant operand addresses of this lane's work items (tile-relative, in doubles)
+  constexpr int W1 = NX * NX + NU * NX + NX + NU, R1 = (W1 + LPA - 1) / LPA;
+  constexpr int W2 = NX * NX + NU * NX + (kLocalQuu ? 0 : NU * NU), R2 = (W2 + LPA - 1) / LPA;
+  int p1[R1], q1[R1], b1[R1], o1[R1];              // pass 1: out = [bias +] sum_k T[p+k] * T[q+k]
+  MAS_UNROLL for (int r = 0; r < R1; ++r) {
+    const int w = lane + r * LPA;
+    int pa = 0, qa = 0, ba = TL::oNegZero, oa = TL::pad_at(TL::oAtV + w);     // idle lanes of the last round: own pad slot
+    if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
+    else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
+    else if (w < NX * NX + NU * NX + NX) { const int i = w - NX * NX - NU * NX; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }
+    else if (w < W1) { const int i = w - NX * NX - NU * NX - NX; pa = TL::oD + L::oB + i * NX; qa = TL::oVx; ba = TL::oD + L::oLu + i; oa = TL::oQu + i; }
+    p1[r] = pa; q1[r] = qa; b1[r] = ba; o1[r] = oa;
+  }
+  int p2[R2], ps2[R2], q2[R2], b2[R2], o2[R2];     // pass 2: out = bias + sum_k T[p + k*ps] * T[q+k]
+  MAS_UNROLL for (int r = 0; r < R2; ++r) {
+    const int w = lane + r * LPA;
+    int pa = 0, ps = 1, qa = 0, ba = 0, oa = TL::pad_at(TL::oQxx + w);
+    if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oAtV + i; ps = NX; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLxx + w; oa = TL::oQxx + w; }
+    else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLux + e; oa = TL::oQux + e; }
+    else if (w < W2) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
+    p2[r] = pa; ps2[r] = ps; q2[r] = qa; b2[r] = ba; o2[r] = oa;
+  }
+
+  // software pipeline: the tiles of step t-1 travel HBM -> registers while step t is computed.  Every lane works for
+  // its OWN agent: lane l fetches element c*16 + l of its agent's tile (chunk c holds the 4 agents' cw-element pieces back
+  // to back, tile_offset) and publishes it to its agent's LDS tile, so each 16-lane write group fills 16 consecutive
+  // doubles.  No predication: a surplus lane of the short last chunk re-reads the piece's last element and publishes it to
+  // its pad slot; fetch and publish are NCH loads and NCH LDS writes with loop-invariant per-lane offsets and one uniform
+  // base pointer that steps back by Np*ND doubles per time step.
+  constexpr int NCH = (ND + kTileChunk - 1) / kTileChunk;
+  static_assert(kTileChunk <= LPA, "one lane per chunk element");
+  double pre[NCH];
+  unsigned fetch_off[NCH]; int publish_at[NCH];
+  MAS_UNROLL for (int c = 0; c < NCH; ++c) {
+    const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
+    const bool mine = lane < cw;
+    const int e = mine ? lane : cw - 1;
+    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(a / 64) * 64 * ND + static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
+    publish_at[c] = tile * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
+  }
+  const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
+  // (uniform base = the tiles of a time step; the agent's 64-block is part of the lane offset, so that listed agents may come from anywhere)
+  const double* tiles_t = D + static_cast<size_t>(d.T - 1) * step_doubles;
+  auto fetch = [&]() { MAS_UNROLL for (int c = 0; c < NCH; ++c) pre[c] = ld_off(tiles_t, fetch_off[c]); };
+  long long regs = 0;
+  // ladder addends of this lane, loop-invariant: reg_q = 1e-6 * 10^q (by repeated multiplication, exactly the
+  // reference's `reg *= 10.0`) for the q < lane rungs it has to apply, -0.0 (adds nothing, changes no bit) after
+  double rung_add[LL - 1];
+  {
+    double reg = 1e-6;
+    MAS_UNROLL for (int q = 0; q < LL - 1; ++q) { rung_add[q] = (q < rung_lane) ? reg : -0.0; reg *= 10.0; }
+  }
+  // gain stores: uniform per-step base pointers + loop-invariant 32-bit byte offsets (row * Np + agent) * 8
+  constexpr int RMX = (NX * NX + LPA - 1) / LPA;
+  unsigned goff[NU], koff[RMX][NU];                  // k rows; this lane's gain column (rows i*NU + m) per round
+  MAS_UNROLL for (int m = 0; m < NU; ++m) goff[m] = static_cast<unsigned>((static_cast<size_t>(m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int r = 0; r < RMX; ++r) {
+    const int w = lane + r * LPA, i = (w < NX * NX) ? (w % NX) : 0;
+    MAS_UNROLL for (int m = 0; m < NU; ++m) koff[r][m] = static_cast<unsigned>((static_cast<size_t>(i * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  }
+  double* kff_t = kff + static_cast<size_t>(d.T - 1) * NU * d.Np;
+  double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
+  fetch();
+
+  // one time step.  The first step is peeled off the loop so that the loop is entered in the state its back edge
+  // has -- tile loads issued, then the gain stores of a step -- and the wait for the tile at the head of the loop can
+  // let the younger stores stay in flight (s_waitcnt vmcnt(#stores)); entered from straight-line code the compiler has
+  // to wait for vmcnt(0) there, which puts every step's store acknowledgements on the serial chain.
+  auto step = [&](int t) {
+    MAS_UNROLL for (int c = 0; c < NCH; ++c) lds[publish_at[c]] = pre[c];
+    if (t > 0) tiles_t -= step_doubles;              // uniform; at t == 0 the (unused) prefetch re-reads step 0
+    MAS_UNROLL for (int c = 0; c < NCH; ++c) MAS_OPAQUE32(fetch_off[c]);
+    MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(goff[m]);
+    MAS_UNROLL for (int r = 0; r < RMX; ++r) { MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(koff[r][m]); }
+    fetch();
+    wave_sync();
+
+    // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
+    {
+      double res[R1];
+      MAS_UNROLL for (int r = 0; r < R1; ++r) {
+        const double s = sum_terms<NX>([&](int k) { return T[p1[r] + k] * T[q1[r] + k]; });
+        res[r] = T[b1[r]] + s;                                        // items without a bias term add -0.0
+      }
+      MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // idle lanes write their own pad slot
+    }
+    wave_sync();
+    double quu[NU * NU], qu[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU];
+    if constexpr (kLocalQuu) {                                        // q_uu = l_uu + (B^T V) B, :119, every lane for itself
+      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+        const int i = e % NU, j = e / NU;
+        double s = 0.0;
+        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[TL::oBtV + i + k * NU] * T[TL::oD + L::oB + j * NX + k];
+        quu[e] = T[TL::oD + L::oLuu + e] + s;
+      }
+    }
+    // ---- pass 2 (second factors of ilqr.hpp:117-119)
+    {
+      double res[R2];
+      MAS_UNROLL for (int r = 0; r < R2; ++r) {
+        const double s = sum_terms<NX>([&](int k) { return T[p2[r] + k * ps2[r]] * T[q2[r] + k]; });
+        res[r] = T[b2[r]] + s;
+      }
+      MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
+      if constexpr (!kLocalQuu && LPA == 16) {
+        // q_uu straight from the lanes that formed it (item NX^2 + NU NX + e sits in round (..) / 16 on lane (..) % 16, and an agent's 16
+        // lanes are one DPP row): the LLT / ladder chain starts without waiting for the LDS round trip of the other pass-2 results
+        tile_gather_quu<NX * NX + NU * NX, R2>(res, quu, std::make_integer_sequence<int, NU * NU>{});
+      }
+    }
+    if constexpr (!kLocalQuu && LPA != 16) {
+      wave_sync();
+      MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
+    }
+    // ---- pass 3 (ilqr.hpp:172-192)
+    {
+      // LLT + x10 regularisation ladder (:172-182), the 16 lanes of an agent trying 16 consecutive
+      // rungs at once: lane r adds reg_0 .. reg_{r-1} to the diagonal in the reference's order (so
+      // its matrix is bit-identical to what the sequential ladder holds at rung r) and factorises it;
+      // the first lane that succeeds is the rung the sequential loop would have stopped at.
+      {
+        double cur[NU * NU];
+        MAS_UNROLL for (int i = 0; i < NU * NU; ++i) cur[i] = quu[i];
+        // the additions stay sequential (floating-point addition is not associative): straight-line code
+        // over the lane's precomputed addends, lane r applying the first r of them
+        MAS_UNROLL for (int q = 0; q < LL - 1; ++q) {
+          MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += rung_add[q];
+        }
+        int win = -1;
+        if constexpr (SharedLadder) {
+          // all agents of the launch move through the ladder together, 16 rungs per agreement
+          double reg_next = 0.0;
+          for (int base = 0, chunk = 0;; base += LL, ++chunk) {
+            if (chunk > 0) {
+              if (chunk == 1) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+              for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
+            }
+            MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
+            const int ok = llt_compute<NU>(Lfac) == 0;
+            unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (!valid) field = 0xFFFFu;                                   // an idle slot never holds the others back
+            MAS_UNROLL for (int sh = LPA; sh < 64; sh <<= 1) field &= static_cast<unsigned>(__shfl_xor(static_cast<int>(field), sh));
+            unsigned agreed;
+            if constexpr (WPB == 1) {
+              agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x));
+            } else if (gridDim.x == 1) {
+              // one workgroup holds the whole problem: LDS and one barrier
+              const unsigned par = agreement_parity; agreement_parity ^= 1u;
+              if (tid == 0) blk_field[par][wave] = field;
+              __syncthreads();
+              unsigned bf = 0xFFFFu;
+              MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
+              agreed = bf;
+            } else if (sync.combine != 0) {
+              // workgroup first (LDS + one barrier), then one wavefront per workgroup across workgroups
+              const unsigned par = agreement_parity; agreement_parity ^= 1u;
+              if (tid == 0) blk_field[par][wave] = field;
+              __syncthreads();
+              if (wave == 0) {
+                unsigned bf = 0xFFFFu;
+                MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[par][wv];
+                const unsigned g = ladder_agree(sync, t * LadderSync::kChunks + chunk, bf, static_cast<int>(gridDim.x));
+                if (tid == 0) blk_agreed[par] = g;
+              }
+              __syncthreads();
+              agreed = blk_agreed[par];
+            } else {
+              // every wavefront of the launch arrives on its own: no workgroup barrier on the way in or out
+              agreed = ladder_agree(sync, t * LadderSync::kChunks + chunk, field, static_cast<int>(gridDim.x) * WPB);
+            }
+            if (agreed != 0u) { win = base + __builtin_ctz(agreed); break; }
+            if (chunk + 1 >= LadderSync::kChunks || base + LL > kRegLadderMax) { win = base + LL - 1; break; }   // guard, never reached (see kRegLadderMax)
+          }
+        } else {
+        // rungs 0..15 first, as straight-line code (three out of four steps need no regularisation at all and
+        // the rest settle within 15 rungs on every workload of this repository) ...
+        {
+          MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = cur[i];
+          const int ok = llt_compute_straight<NU>(Lfac) == 0;
+          const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+          if (field != 0u) win = __builtin_ctz(field);
+        }
+        // ... and the general ladder only if some agent of the wavefront is still unsettled: its lanes go on
+        // with rungs base+16 .. base+31, and so on
+        if (__ballot(win < 0) != 0ull) {
+          double reg_next = 0.0;                                       // this lane's next rung value
+          int base = 0;
+          for (;;) {
+            if (win < 0 && base + LL > kRegLadderMax) win = base + LL - 1;     // guard, never reached (see kRegLadderMax)
+            if (__ballot(win < 0) == 0ull) break;                              // every agent of the wavefront is settled
+            if (win < 0) {
+              if (base == 0) { reg_next = 1e-6; for (int q = 0; q < rung_lane; ++q) reg_next *= 10.0; }
+              for (int q = 0; q < LL; ++q) { MAS_UNROLL for (int i = 0; i < NU; ++i) cur[i * NU + i] += reg_next; reg_next *= 10.0; }
+              base += LL;
+            }
+            double Ltry[NU * NU];
+            MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Ltry[i] = cur[i];
+            const int ok = llt_compute<NU>(Ltry) == 0;
+            const unsigned field = static_cast<unsigned>(__ballot(ok) >> (slot * LPA)) & 0xFFFFu;
+            if (win < 0) {
+              MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = Ltry[i];
+              if (field != 0u) win = base + __builtin_ctz(field);
+            }
+          }
+        }
+        }
+        if (lane == 0 && (!SharedLadder || a == 0)) regs += win;         // the stacked solve counts its rungs once (agent 0)
+        if constexpr (NU <= 2 && LPA == 16) {
+          // the factor of the winning rung straight from its lane (ds_bpermute), see mas_backward_row_kernel
+          const int src = ((tid & ~(LPA - 1)) + (win & (LL - 1))) * 4;
+          MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
+            if (e % NU >= e / NU) {
+              const int lo32 = __builtin_amdgcn_ds_bpermute(src, __double2loint(Lfac[e])), hi32 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(Lfac[e]));
+              Lfac[e] = __hiloint2double(hi32, lo32);
+            }
+          }
+          wave_sync();                                               // the pass-2 outputs before the reads below
+        } else {
+          if (lane == (win & (LL - 1))) { MAS_UNROLL for (int i = 0; i < NU * NU; ++i) T[TL::oL + i] = Lfac[i]; }
+          wave_sync();                                               // also orders the pass-2 outputs before the reads below
+          MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oL + i];
+        }
+      }
+      MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
+      llt_solve_identity<NU>(Lfac, ninv);                           // Quu_reg^-1, :183
+      MAS_UNROLL for (int i = 0; i < NU * NU; ++i) ninv[i] = -ninv[i];
+      MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qu[q]; });   // k = -Quu^-1 q_u, :185
+      // gain stores are unconditional straight-line code: every lane of an agent holds the same k (and every lane
+      // with the same i the same K column), so the duplicates write identical bits to identical addresses, and an
+      // idle slot writes into the unused gain rows of its retired agent: no divergent branch, no exec juggling.
+      MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
+
+      constexpr int RM = (NX * NX + LPA - 1) / LPA;                  // rounds over the v_xx entries
+      MAS_UNROLL for (int r = 0; r < RM; ++r) {
+        const int w = lane + r * LPA;
+        const bool live = valid && (w < NX * NX);
+        const int i = (w < NX * NX) ? (w % NX) : 0;
+        const int j = (w < NX * NX) ? (w / NX) : 0;
+        double quxi[NU], quxj[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) { quxi[m] = T[TL::oQux + i * NU + m]; quxj[m] = T[TL::oQux + j * NU + m]; }
+        const double qxx_own = T[TL::oQxx + j * NX + i], qxx_mir = T[TL::oQxx + i * NX + j], qx_i = T[TL::oQx + i];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // columns i and j of K = -Quu^-1 q_ux, :186
+          Ki[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxi[q]; });
+          Kj[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxj[q]; });
+        }
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // rows i and j of K^T q_uu (unregularised)
+          ktqi[m] = sum_terms<NU>([&](int q) { return Ki[q] * quu[m * NU + q]; });
+          ktqj[m] = sum_terms<NU>([&](int q) { return Kj[q] * quu[m * NU + q]; });
+        }
+        // own entry (i,j) and mirror entry (j,i) of v_xx, :190-191
+        double s, own, mir;
+        s = sum_terms<NU>([&](int m) { return Ki[m] * quxj[m]; });
+        own = qxx_own + s;
+        s = sum_terms<NU>([&](int m) { return quxi[m] * Kj[m]; });
+        own = own + s;
+        s = sum_terms<NU>([&](int m) { return ktqi[m] * Kj[m]; });
+        own = own + s;
+        s = sum_terms<NU>([&](int m) { return Kj[m] * quxi[m]; });
+        mir = qxx_mir + s;
+        s = sum_terms<NU>([&](int m) { return quxj[m] * Ki[m]; });
+        mir = mir + s;
+        s = sum_terms<NU>([&](int m) { return ktqj[m] * Ki[m]; });
+        mir = mir + s;
+        // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: a lower or diagonal
+        // entry averages the old values, an upper entry sees its (already rewritten) mirror
+        const double sym = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));
+        T[live ? (TL::oV + w) : TL::pad_at(TL::oV + w)] = sym;
+        // the lanes of the first tile column (j == 0) also own gain column i and v_x entry i, :186,188-189
+        {
+          double vxi;
+          s = sum_terms<NU>([&](int m) { return Ki[m] * qu[m]; });
+          vxi = qx_i + s;
+          s = sum_terms<NU>([&](int m) { return quxi[m] * kf[m]; });
+          vxi = vxi + s;
+          s = sum_terms<NU>([&](int m) { return ktqi[m] * kf[m]; });
+          vxi = vxi + s;
+          const bool owner = live && j == 0;
+          T[owner ? (TL::oVx + i) : TL::pad_at(TL::oVx + w)] = vxi;
+          MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[r][m], Ki[m]);
+        }
+      }
+    }
+    // the barrier after the next publish orders these writes before pass 1 reads them
+    kff_t -= static_cast<size_t>(NU) * d.Np; Kfb_t -= static_cast<size_t>(NU) * NX * d.Np;
+  };
+  step(d.T - 1);
+  for (int t = d.T - 2; t >= 0; --t) step(t);
+  if (counted && lane == 0) reg_events[a] += regs;
+}
+
+}  // namespace mas

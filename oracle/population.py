@@ -39,3 +39,24 @@ def oracle_variant(O, x0, T=100, dt=0.5, trig="det", sum_order="index", symmetri
         O.set_arith_variant()
 
 
+
+
+def centralized_reading_deviation(O, n_agents, T=100, dt=0.5):
+    """The centralised strategy at C2's horizon, literal stacked solve (centralized.hpp:18-38 + multi_agent_problem.hpp:94-122: finite
+    differences of the SUMMED cost) against the block-diagonal reading the product runs beyond 16 agents, and the literal solve against
+    ITSELF when one input coordinate moves by one ulp: the second is the noise floor the first has to be read against."""
+    x0 = O.single_track_x0(n_agents)
+    lit = O.solve_batch(O.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy="centralized_dense")
+    blk = O.solve_batch(O.MODEL_SINGLE_TRACK, x0, None, T, dt, strategy="centralized")
+    self_dev, self_iters = [], []
+    for column, sign in ((3, +1), (3, -1), (0, +1), (1, -1)):
+        x1 = x0.copy()
+        x1[:, column] = np.nextafter(x1[:, column], sign * np.inf)
+        r = O.solve_batch(O.MODEL_SINGLE_TRACK, x1, None, T, dt, strategy="centralized_dense")
+        self_dev.append(abs(r["total_cost"] - lit["total_cost"]) / abs(lit["total_cost"]))
+        self_iters.append(int(r["iters"][0]))
+    return dict(agents=n_agents, horizon=T,
+                block_diagonal_vs_literal_total_rel=float(abs(blk["total_cost"] - lit["total_cost"]) / abs(lit["total_cost"])),
+                block_diagonal_vs_literal_per_agent_max_rel=float(np.max(np.abs(blk["cost"] - lit["cost"]) / np.abs(lit["cost"]))),
+                iterations_literal=int(lit["iters"][0]), iterations_block_diagonal=int(blk["iters"][0]),
+                literal_under_one_ulp_inputs_total_rel=[float(v) for v in self_dev], literal_under_one_ulp_inputs_iterations=self_iters)

@@ -479,6 +479,20 @@ def test_fused_round_agrees_across_the_line_search_forms(gpu_lib, oracle, model,
     assert new["iters"][sample].tolist() == o["iters"].tolist()
 
 
+@pytest.mark.parametrize("N", [2, 8, 16])
+def test_both_centralised_readings_at_config2s_horizon(gpu_lib, oracle, N):
+    """C2's horizon (H = 100): the reference's literal stacked solve on the device (<= 16 agents) is bit-equal to the oracle's dense
+    restatement, the block-diagonal reading to the oracle's blocked one; how far the two readings lie apart there -- tens of per
+    cent, inside the literal solve's own one-ulp band -- is tests/test_centralized_readings.py (CPU) and bench.py's C2 parity block"""
+    x0 = oracle.single_track_x0(N)
+    for strategy in ("centralized_dense", "centralized"):
+        e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy)
+        o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy=strategy)
+        assert np.array_equal(e["cost"], o["cost"]) and np.array_equal(e["X"], o["X"]) and np.array_equal(e["U"], o["U"]), strategy
+        assert e["iters"].tolist() == o["iters"].tolist() and e["stats"]["reg_events"] == o["stats"]["reg_events"]
+        assert abs(e["total_cost"] - o["total_cost"]) <= 1e-12 * abs(o["total_cost"])
+
+
 @pytest.mark.parametrize("model,N,T", [("MODEL_SINGLE_TRACK", 10, 30), ("MODEL_SINGLE_TRACK", 70, 40), ("MODEL_SINGLE_TRACK", 600, 25),
                                        ("MODEL_LQR_IDENTITY", 40, 20), ("MODEL_SINGLE_TRACK_LANE", 90, 30)])
 def test_centralized_speculative_pass_agrees(gpu_lib, oracle, model, N, T):
