@@ -47,6 +47,23 @@
 #define MAS_DT_FMA(a, b, c) __builtin_fma((a), (b), (c))   /* one rounding: RN(a*b + c) */
 
 /* reduce x to y0 + y1 in [-pi/4, pi/4] (y1 = tail), return the quadrant n mod 4 */
+/* quadrant = (int)fn & 3.  In range (|x| <= MAS_DT_MAX_ARG) fn is an integer below 2^21.  Out of range the result is NaN whatever the
+ * quadrant, but the quadrant still picks that NaN's sign: the device's conversion (v_cvt_i32_f64) SATURATES and maps NaN to 0,
+ * while the C conversion is undefined there (x86 yields INT_MIN) -- so the CPU builds spell the saturation out and both sides
+ * return the same bits for every input.  No instruction is added on the device. */
+MAS_DT_FN int mas_dt_quadrant(double fn) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ((int)fn) & 3;
+#else
+  int n;
+  if (fn != fn) n = 0;
+  else if (fn >= 2147483647.0) n = 2147483647;
+  else if (fn <= -2147483648.0) n = (-2147483647 - 1);
+  else n = (int)fn;
+  return n & 3;
+#endif
+}
+
 MAS_DT_FN int mas_dt_rem_pio2(double x, double* y0, double* y1) {
   const double invpio2 = 0x1.45f306dc9c883p-1;
   const double pio2_1 = 0x1.921fb54400000p+0, pio2_1t = 0x1.0b4611a626331p-34;
@@ -61,7 +78,7 @@ MAS_DT_FN int mas_dt_rem_pio2(double x, double* y0, double* y1) {
   w = fn * pio2_3; r = t - w; w = MAS_DT_FMA(fn, pio2_3t, -((t - r) - w));
   *y0 = r - w;
   *y1 = (r - *y0) - w;
-  return ((int)fn) & 3;
+  return mas_dt_quadrant(fn);
 }
 
 /* sin(x + y) for |x| <= pi/4, |y| << |x| */

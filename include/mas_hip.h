@@ -37,12 +37,17 @@
  *    centralised solve is in flight.  If the barrier starves, the call fails with MAS_HIP_ERR_RUNTIME ("gave up waiting for
  *    the rung agreement") instead of hanging.
  *
- * Two documented departures from a glibc-linked reference binary
- *  - sin/cos/tan come from include/mas_dettrig.h (pure IEEE + - * /, <= 1 ulp from glibc for sin/cos, <= 3 ulp for tan) so
+ * Three documented departures from a glibc-linked reference binary
+ *  - sin/cos/tan come from include/mas_dettrig.h (IEEE + - * / and explicit fused multiply-adds, fma(); <= 1 ulp from glibc for sin/cos, <= 3 ulp for tan) so
  *    that GPU and CPU oracle agree bit for bit.  Its argument range is |x| <= 1.6e6 (three-term Cody-Waite reduction);
  *    beyond it the functions return NaN where glibc returns a value.  A line-search trial that reaches such a heading or
  *    steering angle gets a NaN merit and is rejected (NaN < best is false), and a non-finite accepted cost is flagged with
  *    MAS_HIP_EXIT_NONFINITE.  None of the shipped workloads comes within five orders of magnitude of the limit.
+ *  - divisions by a kernel-invariant divisor (the finite-difference steps 2 eps, eps^2, 4 eps^2; the wheelbase) are formed on the device as
+ *    multiply + exact residual + fused correction + v_div_fixup (div_by, csrc/mas_platform.hpp): the IEEE quotient bit for bit wherever
+ *    the quotient is normal and the residual exactly representable: |p| >= 2^-969 and |p / b| >= 2^-1022, or p == 0
+ *    (tests/hip/div_by_check.hip).  A finite-difference numerator below ~2e-292 -- differences of costs or dynamics of that
+ *    magnitude -- may round differently from `/` in its last bit; no shipped workload comes within 270 orders of magnitude of it.
  *  - max_ms (ilqr.hpp:84-90) is honoured per solve with a clock started on the device when the agent's solve begins; the
  *    check for iteration i+1 is made at the end of iteration i (a few microseconds before the reference's check at the top
  *    of the loop).  All agents of a batch run concurrently, so a budget buys each agent about as many iterations as the

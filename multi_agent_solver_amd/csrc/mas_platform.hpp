@@ -51,9 +51,10 @@ constexpr double kTicksPerMs = 1e5;
 //     q = RN(p y),   r = p - b q  (exact in one fma),   RN(q + r y) = RN(p / b)
 // (Markstein's correction step: q is within one ulp of p / b, so r is exact and the fused correction rounds the true quotient
 // perturbed by less than 2^-53 ulp -- the same last step v_div_fmas_f64 takes in the compiler's own expansion), followed by the
-// hardware's v_div_fixup_f64 for the special operands (zero, infinity, NaN).  Bit-identical to `/` wherever quotient and residual
-// stay clear of the subnormal range (|p / b| >= 2^-960 or p == 0) -- checked against the device's own division on 10^9 random
-// operands by tests/hip/div_by_check.hip, and by every parity test against the CPU oracle, which divides with `/`.
+// hardware's v_div_fixup_f64 for the special operands (zero, infinity, NaN).  Bit-identical to `/` wherever the quotient is normal
+// and the residual exactly representable: |p| >= 2^-969 (r is a multiple of 2^(e_p - 104)) and |p / b| >= 2^-1022, or p == 0 --
+// checked against the device's own division on 10^9 random operands and at that edge by tests/hip/div_by_check.hip, and by every
+// parity test against the CPU oracle, which divides with `/`.  Not guarded at run time: include/mas_hip.h states the limit.
 // The CPU builds (oracle, host emulation) use `/`.
 struct InvDiv { double b, y; };
 MAS_HD constexpr InvDiv make_inv_div(double b) { return InvDiv{b, 1.0 / b}; }

@@ -147,6 +147,12 @@ template <class M>
 class SolverImpl final : public SolverBase {
   static constexpr int NX = M::NX, NU = M::NU;
   static constexpr bool kConstrained = (M::NEQ + M::NIN) > 0;
+  // lanes that share one agent's backward recursion in the LDS-tile kernel
+#if defined(MAS_LPA6)
+  static constexpr int kLanes = (NX > 4) ? MAS_LPA6 : kBackwardLanesPerAgent;      // (A/B builds)
+#else
+  static constexpr int kLanes = kBackwardLanesPerAgent;
+#endif
   // the two-kernel round of mas_fused_hip.hpp.  Finite-difference models: helper wavefronts linearise beside the recursion, NU <= 2
   // only (with NU = 4 the recursion alone fills the 256 VGPRs a wavefront may have when helpers share its SIMD: 54 spilled
   // registers, C4 17.3 -> 21.5 ms).  Models whose derivatives are all analytic: the recursion's lanes evaluate them in registers.
@@ -259,6 +265,14 @@ class SolverImpl final : public SolverBase {
   void save_initial() override {
     be.d2d(x0_saved, x0, sizeof(double) * NX * d.Np); be.d2d(U_saved, U, sizeof(double) * d.T * NU * d.Np); saved = true;
     saved_controls_zero = controls_zero;
+    // the rollout and cost of these controls (OCP::initialize_problem, ocp.hpp:102-183 -- problem set-up, which the reference's examples
+    // do before they start their clock, examples/multi_agent_single_track.cpp:113-123) are saved with them, so that a restore is three
+    // copies instead of a T-step rollout chain
+    saved_rollout = initialized && rollout_consistent;
+    if (saved_rollout) {
+      if (!X_saved) { X_saved = dalloc(static_cast<size_t>(d.T + 1) * NX * d.Np); cost_saved = dalloc(d.Np); }
+      be.d2d(X_saved, X, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(cost_saved, cost, sizeof(double) * d.Np);
+    }
   }
   void restore_initial() override {
     require(saved, "no saved initial state");
@@ -266,7 +280,14 @@ class SolverImpl final : public SolverBase {
     controls_zero = saved_controls_zero;
     be.zero(iters_total, sizeof(int) * d.Np);   // per-agent iteration counts restart with the problem; reg_events keeps counting since reset_stats (no read-back here)
     have_x0 = true;
-    initialize_problem();
+    if (saved_rollout && !(kConstrained && al_enabled)) {
+      be.d2d(X, X_saved, sizeof(double) * (d.T + 1) * NX * d.Np); be.d2d(cost, cost_saved, sizeof(double) * d.Np);
+      be.d2d(merit, cost_saved, sizeof(double) * d.Np);         // current merit == objective without constraint functions (ilqr.hpp:379-407)
+      if (!radii) radii = dalloc(d.Np);
+      initialized = true; rollout_consistent = true;
+    } else {
+      initialize_problem();
+    }
   }
 
   // ---------------------------------------------------------------- N x iLQR::solve ------
@@ -697,7 +718,7 @@ class SolverImpl final : public SolverBase {
       MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
       LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
       sy.combine = switches.central_combine;
-      constexpr int apw = 64 / kBackwardLanesPerAgent;
+      constexpr int apw = 64 / kLanes;
       be.begin("central_backward", bytes);
       const int wpb = central_waves_per_block();
       auto launch = [&](auto kernel, int w) {
@@ -737,10 +758,10 @@ class SolverImpl final : public SolverBase {
       return;
     }
     be.begin("backward", bytes);
-    constexpr int apw = 64 / kBackwardLanesPerAgent;
+    constexpr int apw = 64 / kLanes;
     constexpr int wpb = kBackwardWavesPerBlock;       // four wavefronts per workgroup: one per SIMD of a CU (mas_kernels_hip.hpp)
     const dim3 grid((hi - lo + wpb * apw - 1) / (wpb * apw));
-    if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) {     // registers + DPP form (no LDS for V and the tiles)
+    if constexpr (NX == 4 && kLanes == 16) {     // registers + DPP form (no LDS for V and the tiles)
       if (!backward_tile_forced()) {
         be.launch_kernel(mas_backward_row_kernel<M, false, wpb>, grid, dim3(64 * wpb), d, P, X, D, kff, Kfb, reg_events, active, lo, hi, LadderSync{});
         be.end();
@@ -753,7 +774,7 @@ class SolverImpl final : public SolverBase {
       extras.live_list = live_list; extras.live_count = live_count;
       tile_grid = dim3(static_cast<unsigned>((slots + wpb * apw - 1) / (wpb * apw)));
     }
-    be.launch_kernel(mas_backward_tile_kernel<M, kBackwardLanesPerAgent, false, wpb>, tile_grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
+    be.launch_kernel(mas_backward_tile_kernel<M, kLanes, false, wpb>, tile_grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
                      reg_events, active, lo, hi, extras);
     be.end();
 #endif
@@ -764,16 +785,16 @@ class SolverImpl final : public SolverBase {
   using BackwardKernelFn = void (*)(Dims, ModelParams, const double*, const double*, double*, double*, long long*, const int*, int, int, LadderSync);
   template <int W>
   BackwardKernelFn central_kernel() const {
-    if constexpr (NX == 4 && kBackwardLanesPerAgent == 16) {
+    if constexpr (NX == 4 && kLanes == 16) {
       if (!backward_tile_forced()) {
         if (!central_pipelined()) return mas_backward_row_kernel<M, true, W>;
         return mas_backward_row_pipelined_kernel<M, W>;
       }
     }
-    return mas_backward_tile_kernel<M, kBackwardLanesPerAgent, true, W>;
+    return mas_backward_tile_kernel<M, kLanes, true, W>;
   }
   bool central_pipelined() const {                                     // false = the plain registers + DPP kernel with the shared ladder
-    if constexpr (!(NX == 4 && kBackwardLanesPerAgent == 16)) return false;
+    if constexpr (!(NX == 4 && kLanes == 16)) return false;
     return !backward_tile_forced() && switches.central_pipeline;
   }
   bool backward_list_enabled() const { return switches.backward_list; }
@@ -792,7 +813,7 @@ class SolverImpl final : public SolverBase {
   bool ladder_resident() {
     if (ladder_resident_checked) return ladder_resident_ok;
     ladder_resident_checked = true;
-    constexpr int apw = 64 / kBackwardLanesPerAgent;
+    constexpr int apw = 64 / kLanes;
     const int wpb = central_waves_per_block();
     const int grid = (d.N + apw * wpb - 1) / (apw * wpb);
     int per_cu = 0; hipDeviceProp_t prop;
@@ -1111,6 +1132,7 @@ class SolverImpl final : public SolverBase {
   double *x0 = nullptr, *X = nullptr, *U = nullptr, *D = nullptr, *kff = nullptr, *Kfb = nullptr, *Xs = nullptr, *Us = nullptr;
   double *trial_merit = nullptr, *cost = nullptr, *merit = nullptr, *x0_saved = nullptr, *U_saved = nullptr, *stage = nullptr;
   double *Dsoa = nullptr;
+  double *X_saved = nullptr, *cost_saved = nullptr; bool saved_rollout = false;   // rollout and cost of the saved initial controls
   double *dense_ws = nullptr; size_t dense_ws_size = 0; int *dense_flags = nullptr;   // literal stacked solve (mas_dense.hpp)
   double *al_lam = nullptr, *al_mu = nullptr, *al_rho = nullptr, *improvement = nullptr, *trial_obj = nullptr;
   bool al_enabled = true, al_rho_dirty = false;

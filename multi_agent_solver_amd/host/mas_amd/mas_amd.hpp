@@ -203,7 +203,7 @@ class iLQR {
   // copies are independent solver objects (the reference stores them in std::vector<Solver>, nash.hpp:78-83, and calls
   // them from different OpenMP threads): a copy starts without a device handle of its own, it never shares one
   iLQR(const iLQR& o) : last_iterations(o.last_iterations), last_exit(o.last_exit), params_(o.params_) {}
-  iLQR& operator=(const iLQR& o) { if (this != &o) { params_ = o.params_; last_iterations = o.last_iterations; last_exit = o.last_exit; cache_.clear(); } return *this; }
+  iLQR& operator=(const iLQR& o) { if (this != &o) { params_ = o.params_; last_iterations = o.last_iterations; last_exit = o.last_exit; cache_.clear(); pushed_to_ = nullptr; } return *this; }
   iLQR(iLQR&&) = default;
   iLQR& operator=(iLQR&&) = default;
   void set_params(const SolverParams& params) {
@@ -219,7 +219,9 @@ class iLQR {
   // also keeps the augmented-Lagrangian multipliers and penalty across calls (ilqr.hpp:415-421).
   void solve(OCP& problem) {
     detail::Batch& b = cache_.get({problem.model, 1, problem.horizon_steps, problem.dt, problem.input_lower_bounds, problem.input_upper_bounds});
-    b.set_params(params_);
+    // parameters go to the handle when it is new or they changed, not on every call: the reference sets penalty_parameter in
+    // set_params ONCE and lets it grow across solves (ilqr.hpp:47-48,256-259); re-sending "penalty" would reset it
+    if (pushed_to_ != b.get() || !(pushed_params_ == params_)) { b.set_params(params_); pushed_to_ = b.get(); pushed_params_ = params_; }
     if (problem.best_controls.rows() != problem.control_dim || problem.best_controls.cols() != problem.horizon_steps)
       problem.best_controls = ControlTrajectory::Zero(problem.control_dim, problem.horizon_steps);
     b.check(mas_hip_set_initial_states_host(b.get(), problem.initial_state.data()), "set_initial_states");
@@ -233,7 +235,8 @@ class iLQR {
   }
   int last_iterations = 0, last_exit = 0;          // extension: the reference exposes neither
  private:
-  SolverParams params_;
+  SolverParams params_, pushed_params_;
+  const void* pushed_to_ = nullptr;               // the handle `pushed_params_` were last sent to
   detail::BatchCache cache_;
 };
 
