@@ -147,7 +147,7 @@ int mas_hip_initialize_problem(mas_hip_solver*);
 /* snapshot / restore of (x0, controls) on the device, so a benchmark can repeat a run with
  * its inputs already resident in HBM */
 int mas_hip_save_initial(mas_hip_solver*);
-int mas_hip_restore_initial(mas_hip_solver*);
+int mas_hip_restore_initial(mas_hip_solver*);   /* enqueued on the handle's stream (returns before the copies have run) */
 
 /* ---- the hot path ---- */
 /* N x iLQR::solve (ilqr.hpp:58-273) == first loop of detail::sequential_solve, nash.hpp:59-64 */

@@ -131,7 +131,7 @@ int mas_hip_set_initial_states_device(mas_hip_solver* h, const void* x0) {
 int mas_hip_set_controls_device(mas_hip_solver* h, const void* U) { return guarded(h, [&](mas::SolverBase& s) { s.set_controls(static_cast<const double*>(U), true); }); }
 int mas_hip_initialize_problem(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.initialize_problem(); s.be.sync(); }); }
 int mas_hip_save_initial(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.save_initial(); s.be.sync(); }); }
-int mas_hip_restore_initial(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.restore_initial(); s.be.sync(); }); }
+int mas_hip_restore_initial(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.restore_initial(); }); }   // stream-ordered: device-to-device copies on the handle's stream, nothing the host could read
 
 int mas_hip_solve(mas_hip_solver* h) { return guarded(h, [&](mas::SolverBase& s) { s.solve(); }); }
 int mas_hip_run_sequential(mas_hip_solver* h, int max_outer) { return guarded(h, [&](mas::SolverBase& s) { s.run_sequential(max_outer); }); }
