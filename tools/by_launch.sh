@@ -4,7 +4,7 @@
 W=${1:-c3}; N=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/bylaunch_$W
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/bylaunch_$W -o t -- python3 tools/exp/one_run.py $W $N > gpurun_out/bylaunch_$W.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/bylaunch_$W -o t -- python3 tools/one_run.py $W $N > gpurun_out/bylaunch_$W.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 rows = []

@@ -111,7 +111,7 @@ if f_csv and w_csv:
     ft, fn, ff, _ = counters(f_csv)
     wt, wn, wf, _ = counters(w_csv)
     out = dict(meta)
-    out["_what"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over ONE strategy run (tools/exp/one_run.py); counters are in KiB; "
+    out["_what"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over ONE strategy run (tools/one_run.py); counters are in KiB; "
                     "FETCH_SIZE is doubled (gfx950 reports 1/2 of a coalesced streaming read, MI355X_MICROARCH.md), WRITE_SIZE taken as is; "
                     "algorithmic bytes: the same run's per-kernel totals (SURVEY.md 8(d) per agent x active agents per launch)")
     out["kernels"] = {}
@@ -139,7 +139,7 @@ for p in sorted(glob.glob(os.path.join(D, "sq*/**/*counter_collection.csv"), rec
         dur[k] = ns[k]
 if sq:
     out = dict(meta)
-    out["_what"] = ("rocprofv3 --pmc SQ counter sets (four passes) over ONE strategy run (tools/exp/one_run.py), summed over every dispatch of a kernel; "
+    out["_what"] = ("rocprofv3 --pmc SQ counter sets (four passes) over ONE strategy run (tools/one_run.py), summed over every dispatch of a kernel; "
                     "SQ cycle counters count quad-cycles per wavefront.  derived: issue = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, valu_issue = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, "
                     "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, lds_bank_conflict = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS, cycles_per_valu = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, "
                     "chip_valu_busy = 4 * SQ_ACTIVE_INST_VALU / (kernel ns under the profiler * 2.4 GHz * 1024 SIMDs) -- the FP64 VALU issue slots of the whole chip the kernel fills (no MFMA is used)")
