@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU: random models, agent counts, horizons, strategies, warm starts, bounds and iteration
-limits, every result compared bit for bit with the CPU oracle (det trig).  Not part of the test suite (run time grows with
+limits and kernel forms (fused / five-kernel rounds, one- / four-lane line search), every result compared bit for bit with the CPU oracle (det trig).  Not part of the test suite (run time grows with
 the case count); the fixed-seed tests cover the same code paths with chosen cases.
 usage: python tools/fuzz_parity.py [cases] [seed]"""
 import math
@@ -50,7 +50,12 @@ for c in range(cases):
     else:
         x0 = rng.standard_normal((N, nx))
     U0 = None if rng.random() < 0.4 or strategy.startswith("centralized") else 0.1 * rng.standard_normal((N, T, nu))
+    # kernel forms (bit-identical alternatives, mas_hip_set_option): two-kernel fused rounds or the five-kernel round, the four-lane line
+    # search never / up to 1600 live agents / always
+    forms = {"fused": int(rng.choice([0, 1, 1, 1])), "forward_quad_max": int(rng.choice([0, 1600, 1600, 1000000]))}
     with BatchSolver(model, N, T, DT[model]) as s:
+        for key, value in forms.items():
+            s.set_option(key, value)
         s.set_params({"max_iterations": max_it, "tolerance": tol, "max_ms": math.inf})
         s.set_initial_states(x0); s.set_controls(U0); s.initialize_problem()
         s.run(strategy, max_outer)
@@ -65,6 +70,6 @@ for c in range(cases):
         ok = ok and (e["status"] & 3).tolist() == o["status"].tolist()
     if not ok:
         bad += 1
-        print("MISMATCH", dict(case=c, model=model, strategy=strategy, N=N, T=T, max_outer=max_outer, max_it=max_it, tol=tol, warm=U0 is not None))
+        print("MISMATCH", dict(case=c, model=model, strategy=strategy, N=N, T=T, max_outer=max_outer, max_it=max_it, tol=tol, warm=U0 is not None, **forms))
 print(f"{cases} cases, seed {seed}: {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
