@@ -7,7 +7,8 @@
 // and the first kernel does, per workgroup of 16 consecutive agents,
 //   phase 0   select of the PREVIOUS round for its 16 agents (SelectBody: acceptance, termination, counters, next live list)
 //   helpers   HELPERS wavefronts linearise the workgroup's (agent, t) items in REVERSE time, four time steps of the 16 agents per
-//             wavefront pass (lane = (agent, dt)), and hand the derivative tiles to the backward wavefronts through a ring of
+//             wavefront pass (lane = (agent, dt); the first chunk shared out among three of them by blocks of the tile, so that the
+//             recursion starts sooner), and hand the derivative tiles to the backward wavefronts through a ring of
 //             RING chunk slots in LDS -- the tiles (46 KB per agent and iteration, 90 % of the unfused sweep's HBM traffic and all
 //             of the backward pass's reads) never leave the CU.  The same lanes commit the trial the select accepted: they read
 //             x_t, u_t from the trial plane and store them to X, U (ilqr.hpp:231-232) while they linearise there.
@@ -45,7 +46,9 @@ struct FusedCtl {
   int ready[4];                  // ready[s] = n + 1 once chunk n lies complete in ring slot s = n % RING
   int consumed[4];               // chunks backward wavefront w has finished reading (its data has arrived)
   int act[kFusedAgents], selj[kFusedAgents], col[kFusedAgents];
-  int any_act, any_pend, pad0, pad1;
+  int any_act, any_pend;
+  int pad0;
+  int parts_done;                // helpers that have written their blocks of chunk 0
 };
 
 template <class M, int HELPERS, int RING>
@@ -409,12 +412,37 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
 }
 
 // ---- one helper wavefront: commit + linearisation of the workgroup's items, chunk by chunk in reverse time ----
+// The recursion cannot start before chunk 0 (the last four time steps) lies in the ring, and one item is ~1,400 dependent FP64
+// instructions (~6 us for a lone wavefront).  So chunk 0 is SHARED OUT BY BLOCKS of the tile: helper 0 evaluates A and B, helper 1
+// l_xx, helper 2 l_x, l_u, l_uu, l_ux (552 / 457 / 465 instructions: ~2.4 us), each writes its elements of the 64 tiles, and the
+// last of the three to finish publishes the chunk; the remaining helper starts on chunk 1 at once, the others follow with chunks 2, 3,
+// 4 and from there every helper takes every fourth chunk.  Same functions, same operands: identical tiles.
+template <int PARTS, class L>
+struct PartRange {                 // the elements of a tile the blocks in PARTS cover: up to two runs [lo1, hi1) and [lo2, hi2) (tile order: A B l_x l_u l_xx l_uu l_ux)
+  static constexpr bool kAB = (PARTS & kLinA) != 0, kXX = (PARTS & kLinLxx) != 0;
+  static constexpr int lo1 = kAB ? L::oA : kXX ? L::oLxx : L::oLx, hi1 = kAB ? L::oLx : kXX ? L::oLuu : L::oLxx;
+  static constexpr int lo2 = (kAB || kXX) ? 0 : L::oLuu, hi2 = (kAB || kXX) ? 0 : L::oCore;
+  template <class F> __device__ static void for_each(F f) {
+    MAS_UNROLL for (int e = lo1; e < hi1; ++e) f(e);
+    MAS_UNROLL for (int e = lo2; e < hi2; ++e) f(e);
+  }
+};
 template <class M, int HELPERS, int RING>
 __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelParams& P, double* __restrict__ lds, FusedCtl* ctl, int h, int a_base,
                                                   double* __restrict__ X, double* __restrict__ U, const FusedRound& fr) {
   using FL = FusedLayout<M, HELPERS, RING>;
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, ND = L::ND, TS = FL::TS;
+  // the three groups of chunk 0 (helpers beyond the third take whole chunks from the start)
+  constexpr int kGroup0 = kLinA | kLinB, kGroup1 = kLinLxx, kGroup2 = kLinLx | kLinLu | kLinLuu | kLinLux;
+#if defined(MAS_FUSED_NO_SHARED_FIRST_CHUNK)
+  constexpr bool kShareFirst = false;                                  // (A/B builds)
+#else
+  constexpr bool kShareFirst = HELPERS >= 4 && ND == L::oCore;         // (unconstrained tiles; with fewer helpers nobody would be left for chunk 1)
+#endif
+  static_assert((PartRange<kGroup0, L>::hi1 - PartRange<kGroup0, L>::lo1) + (PartRange<kGroup1, L>::hi1 - PartRange<kGroup1, L>::lo1) +
+                (PartRange<kGroup2, L>::hi1 - PartRange<kGroup2, L>::lo1) + (PartRange<kGroup2, L>::hi2 - PartRange<kGroup2, L>::lo2) == L::oCore,
+                "the three groups cover a tile exactly once");
   const int l = static_cast<int>(threadIdx.x) & 63, al = l & 15, dt = l >> 4, a = a_base + al;
   const bool act = ctl->act[al] != 0;
   const int jsel = ctl->selj[al];
@@ -426,22 +454,47 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
   const unsigned col = static_cast<unsigned>(ctl->col[al]);
   double* ring = lds + FL::oRing;
   const int C = (d.T + 3) >> 2;
-  for (int n = h; n < C; n += HELPERS) {
-    const int t = 4 * (C - 1 - n) + dt;
-    const bool in = t < d.T;
-    double x[NX], u[NU];
+  auto load_xu = [&](int t, bool wanted, double* x, double* u) {
     MAS_UNROLL for (int q = 0; q < NX; ++q) x[q] = 0.0;
     MAS_UNROLL for (int q = 0; q < NU; ++q) u[q] = 0.0;
-    if (in && (act || pend)) {
+    if (wanted) {
       MAS_UNROLL for (int q = 0; q < NX; ++q) x[q] = (Xsrc + (static_cast<size_t>(t) * NX + q) * d.Np)[col];
       MAS_UNROLL for (int q = 0; q < NU; ++q) u[q] = (Usrc + (static_cast<size_t>(t) * NU + q) * d.Np)[col];
     }
-    if (in && pend) {                                                  // x = best_x; u = best_u, ilqr.hpp:231-232
-      MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, t * NX + q, a) = x[q];
-      MAS_UNROLL for (int q = 0; q < NU; ++q) MAS_AT(U, t * NU + q, a) = u[q];
-      if (t == d.T - 1) { MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, d.T * NX + q, a) = (Xsrc + (static_cast<size_t>(d.T) * NX + q) * d.Np)[col]; }
-    }
-    if (!any_act) continue;                                            // uniform: a workgroup of retired agents only commits
+  };
+  auto commit = [&](int t, const double* x, const double* u) {         // x = best_x; u = best_u, ilqr.hpp:231-232
+    MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, t * NX + q, a) = x[q];
+    MAS_UNROLL for (int q = 0; q < NU; ++q) MAS_AT(U, t * NU + q, a) = u[q];
+    if (t == d.T - 1) { MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, d.T * NX + q, a) = (Xsrc + (static_cast<size_t>(d.T) * NX + q) * d.Np)[col]; }
+  };
+  // the blocks PARTS of chunk 0: elements [lo, hi) of this lane's tile
+  auto share_of_first_chunk = [&](auto parts_tag, bool commits) {
+    constexpr int PARTS = decltype(parts_tag)::value;
+    using R = PartRange<PARTS, L>;
+    const int t = 4 * (C - 1) + dt;
+    const bool in = t < d.T;
+    double x[NX], u[NU];
+    load_xu(t, in && (act || pend), x, u);
+    if (commits && in && pend) commit(t, x, u);
+    if (!any_act) return;
+    double Dl[ND];
+    R::for_each([&](int e) { Dl[e] = 0.0; });
+    if (in && act) linearise<M, PARTS>(x, u, t, Dl, P);
+    double* tile = ring + static_cast<size_t>(l) * TS;                 // chunk 0 -> slot 0
+    R::for_each([&](int e) { tile[e] = Dl[e]; });
+    if (fr.D_dump && in && act) R::for_each([&](int e) { MAS_TILE_AT(fr.D_dump, ND, t, a, e) = Dl[e]; });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int before = 0;
+    if (l == 0) before = atomicAdd(&ctl->parts_done, 1);               // LDS atomic: the last of the three publishes the chunk
+    if (__builtin_amdgcn_readfirstlane(before) == 2 && l == 0) ctl->ready[0] = 1;
+  };
+  auto whole_chunk = [&](int n) {
+    const int t = 4 * (C - 1 - n) + dt;
+    const bool in = t < d.T;
+    double x[NX], u[NU];
+    load_xu(t, in && (act || pend), x, u);
+    if (in && pend) commit(t, x, u);
+    if (!any_act) return;                                              // uniform: a workgroup of retired agents only commits
     double Dl[ND];
     if (in && act) linearise<M>(x, u, t, Dl, P);
     else { MAS_UNROLL for (int e = 0; e < ND; ++e) Dl[e] = 0.0; }
@@ -453,7 +506,17 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
     if (fr.D_dump && in && act) { MAS_UNROLL for (int e = 0; e < ND; ++e) MAS_TILE_AT(fr.D_dump, ND, t, a, e) = Dl[e]; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (l == 0) ctl->ready[n % RING] = n + 1;
+  };
+  if constexpr (kShareFirst) {
+    if (h == 0) share_of_first_chunk(std::integral_constant<int, kGroup0>{}, true);
+    else if (h == 1) share_of_first_chunk(std::integral_constant<int, kGroup1>{}, false);
+    else if (h == 2) share_of_first_chunk(std::integral_constant<int, kGroup2>{}, false);
   }
+  // whole chunks, statically dealt: with chunk 0 shared out, the helper that has no share of it starts on chunk 1 at once and the
+  // others follow with chunks 2, 3, 4 (a queue in LDS -- atomicAdd per grab -- was tried first: the kernel never finished, cause
+  // not found)
+  const int first = kShareFirst ? ((h + 1) % HELPERS) + 1 : h;
+  for (int n = first; n < C; n += HELPERS) whole_chunk(n);
 }
 
 // ---- commit of the accepted trials of a workgroup's 16 agents by one wavefront (models without linearising helpers) ----
@@ -503,6 +566,7 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
     const unsigned long long am = __ballot(act != 0), pm = __ballot(jsel >= 0);
     if (lane == 0) { ctl->any_act = am != 0ull; ctl->any_pend = pm != 0ull; }
     if (lane < 4) { ctl->ready[lane] = 0; ctl->consumed[lane] = 0; }
+    if (lane == 0) ctl->parts_done = 0;
   }
   __syncthreads();
   // counters and the next round's live list (two atomics, one of them returning) AFTER the barrier: the helpers are on their

@@ -58,13 +58,17 @@ MAS_HD void clamp_column(double* u, const double* lb, const double* ub) {
 // One (agent, t): ilqr.hpp:106-113 through the hooks OCP::initialize_problem installs
 // (ocp.hpp:117-135): central differences of finite_differences.hpp:53-287 unless the
 // workload's example wires an analytic hook.  D is laid out as DerivLayout<M>.
-template <class M>
+// PARTS: which blocks of the tile to evaluate (the others are left untouched): the helper wavefronts of the fused kernel share the
+// FIRST chunks of a launch out among themselves by block, so that the recursion can start sooner (mas_fused_hip.hpp)
+enum LinPart : int { kLinA = 1, kLinB = 2, kLinLx = 4, kLinLu = 8, kLinLxx = 16, kLinLuu = 32, kLinLux = 64, kLinConstraints = 128, kLinAll = 255 };
+template <class M, int PARTS = kLinAll>
 MAS_HD void linearise(const double* x, const double* u, int t, double* D, const ModelParams& P) {
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU;
   double xp[NX], xm[NX], up[NU], um[NU], fp[NX], fm[NX];
 
-  if constexpr (M::kAnalyticA) {
+  if constexpr (!(PARTS & kLinA)) {
+  } else if constexpr (M::kAnalyticA) {
     M::A(x, u, D + L::oA, P);
   } else {                                              // finite_differences.hpp:53-71, eps = 1e-6
     const double eps = 1e-6;
@@ -74,7 +78,8 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oA + i * NX + r] = div_by(fp[r] - fm[r], make_inv_div(2 * eps));
     }
   }
-  if constexpr (M::kAnalyticB) {
+  if constexpr (!(PARTS & kLinB)) {
+  } else if constexpr (M::kAnalyticB) {
     M::B(x, u, D + L::oB, P);
   } else {                                              // :73-92
     const double eps = 1e-6;
@@ -84,7 +89,8 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       MAS_UNROLL for (int r = 0; r < NX; ++r) D[L::oB + i * NX + r] = div_by(fp[r] - fm[r], make_inv_div(2 * eps));
     }
   }
-  if constexpr (M::kAnalyticLx) {
+  if constexpr (!(PARTS & kLinLx)) {
+  } else if constexpr (M::kAnalyticLx) {
     M::lx(x, u, t, D + L::oLx, P);
   } else {                                              // :110-122 (no safe_eval on gradients)
     const double eps = 1e-6;
@@ -93,7 +99,8 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       D[L::oLx + i] = div_by(M::stage_cost(xp, u, t, P) - M::stage_cost(xm, u, t, P), make_inv_div(2 * eps));
     }
   }
-  if constexpr (M::kAnalyticLu) {
+  if constexpr (!(PARTS & kLinLu)) {
+  } else if constexpr (M::kAnalyticLu) {
     M::lu(x, u, t, D + L::oLu, P);
   } else {                                              // :124-136
     const double eps = 1e-6;
@@ -102,7 +109,8 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       D[L::oLu + i] = div_by(M::stage_cost(x, up, t, P) - M::stage_cost(x, um, t, P), make_inv_div(2 * eps));
     }
   }
-  if constexpr (M::kAnalyticLxx) {
+  if constexpr (!(PARTS & kLinLxx)) {
+  } else if constexpr (M::kAnalyticLxx) {
     M::lxx(x, u, t, D + L::oLxx, P);
   } else {                                              // :138-173, eps = 1e-5, (i,j) and (j,i) separately
     const double eps = 1e-5;
@@ -125,7 +133,8 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       }
     }
   }
-  if constexpr (M::kAnalyticLuu) {
+  if constexpr (!(PARTS & kLinLuu)) {
+  } else if constexpr (M::kAnalyticLuu) {
     M::luu(x, u, t, D + L::oLuu, P);
   } else {                                              // :175-210
     const double eps = 1e-5;
@@ -148,7 +157,8 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       }
     }
   }
-  if constexpr (M::kAnalyticLux) {
+  if constexpr (!(PARTS & kLinLux)) {
+  } else if constexpr (M::kAnalyticLux) {
     M::lux(x, u, t, D + L::oLux, P);
   } else {                                              // :263-287, eps = 1e-6, H is nu x nx
     const double eps = 1e-6;
@@ -165,7 +175,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
     }
   }
   // function constraints: residual and central-difference Jacobians (finite_differences.hpp:289-345, eps = 1e-6)
-  if constexpr (M::NEQ > 0) {
+  if constexpr (M::NEQ > 0 && (PARTS & kLinConstraints)) {
     const double eps = 1e-6;
     double cp[M::NEQ], cm[M::NEQ];
     M::equality(x, u, D + L::oEq, P);
@@ -180,7 +190,7 @@ MAS_HD void linearise(const double* x, const double* u, int t, double* D, const 
       MAS_UNROLL for (int r = 0; r < M::NEQ; ++r) D[L::oEqJu + i * M::NEQ + r] = div_by(cp[r] - cm[r], make_inv_div(2 * eps));
     }
   }
-  if constexpr (M::NIN > 0) {
+  if constexpr (M::NIN > 0 && (PARTS & kLinConstraints)) {
     const double eps = 1e-6;
     double cp[M::NIN], cm[M::NIN];
     M::inequality(x, u, D + L::oIn, P);
