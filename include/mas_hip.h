@@ -19,7 +19,10 @@
  *  - `*_host` entry points take host pointers (one PCIe copy each way); `*_device` ones take
  *    device pointers in the same layout (used with torch tensors' data_ptr());
  *  - a handle is bound to one HIP device and one stream and is not thread-safe
- *    (one handle per GPU, as one rank per GPU under torch.distributed).
+ *    (one handle per GPU, as one rank per GPU under torch.distributed; several handles may be driven from several host threads);
+ *  - while mas_hip_solve / mas_hip_run_* execute, the calling thread POLLS one pinned 64-bit word per round of kernels (the device publishes
+ *    each round's counters as a single store; an event per round cost 6 us of device idle time per round): one host core is busy for the
+ *    duration of the call, which returns after the handle's stream has drained.
  *
  * Stream ordering of the `*_device` entry points
  *    A handle made by mas_hip_create works on its OWN non-blocking stream; one made by mas_hip_create_on_stream works on

@@ -589,10 +589,10 @@ struct TrustNormBody {
     double ss = 0.0;                                   // delta.norm(): Frobenius, column-major order (nash.hpp:216-217)
     const int R = d.T * NU;
     int r = 0;
-    for (; r + 8 <= R; r += 8) {                       // eight loads in flight, the additions stay in order
-      double dl[8];
-      MAS_UNROLL for (int q = 0; q < 8; ++q) dl[q] = MAS_AT(U, r + q, a) - MAS_AT(U_old, r + q, a);
-      MAS_UNROLL for (int q = 0; q < 8; ++q) ss += dl[q] * dl[q];
+    for (; r + 16 <= R; r += 16) {                     // 32 loads in flight (a lane walking the rows alone pays a memory round trip per batch), the additions stay in order
+      double dl[16];
+      MAS_UNROLL for (int q = 0; q < 16; ++q) dl[q] = MAS_AT(U, r + q, a) - MAS_AT(U_old, r + q, a);
+      MAS_UNROLL for (int q = 0; q < 16; ++q) ss += dl[q] * dl[q];
     }
     for (; r < R; ++r) { const double dl = MAS_AT(U, r, a) - MAS_AT(U_old, r, a); ss += dl * dl; }
     const double norm = sqrt(ss);

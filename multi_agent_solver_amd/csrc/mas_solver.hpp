@@ -909,6 +909,13 @@ class SolverImpl final : public SolverBase {
     // waste its run-ahead round, so run ahead only while the previous solve needed several rounds
     const bool run_ahead = !debug && (n_solves > 1 || last_solve_rounds != 1);
 #endif
+    // the host polls the round's packed word (no event between rounds: an event record costs ~6 us of device idle time per round);
+    // rounds whose counters change after the commit (multiplier update) or that are inspected afterwards (debug) keep the event
+#if defined(MAS_HOST_EMULATION)
+    const bool poll = false;
+#else
+    const bool poll = !debug && !(kConstrained && al_enabled) && d.N < (1 << 24);
+#endif
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
     auto enqueue = [&](int r) {
@@ -938,7 +945,8 @@ class SolverImpl final : public SolverBase {
       be.template launch_1d<1>("select", sel, d.N);
       // the round's counters reach the host through the commit kernel (Publish); the multiplier update of constrained models
       // still changes them after the commit, so those rounds keep the copy
-      const Publish pub = al_round ? Publish{} : Publish{ctr, host_counters + 2 * (r % kCounterRing), 2};
+      Publish pub = al_round ? Publish{} : Publish{ctr, host_counters + 2 * (r % kCounterRing), 2};
+      if (poll) { pub = Publish{ctr, host_counters + 16 + (r % kCounterRing), 2}; pub.tag = static_cast<int>((r + 1) & 0x7FFF); }   // one packed word, polled by the host
       if (by_slot) be.template launch_2d<4>("commit", CommitSlotBody<M>{d, Xs, Us, alpha_sel, X, U, list_now, live, pub}, static_cast<int>(live_upper), d.T + 1);
       else be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
       if (trust_epilogue) {
@@ -954,22 +962,29 @@ class SolverImpl final : public SolverBase {
                                                                reinterpret_cast<int*>(ctr), ctr + 1, timed ? solve_start : nullptr, max_ms}, d.N);
       }
       if (al_round) be.d2h_async(host_counters + 2 * (r % kCounterRing), ctr, sizeof(long long) * 2);
-      be.record(round_ev[r & 1]);
+      if (!poll) be.record(round_ev[r & 1]);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
     };
     long long n_before = d.N;
     live_upper = d.N;
     int enq = 0, rounds_this_solve = 0;
+    if (poll) clear_round_words();
     // the first check of a solve sees elapsed_ms == 0, so only a negative budget stops it before its first iteration
     if (max_iterations > 0 && !(timed && 0.0 > max_ms)) { enqueue(0); enq = 1; }
     else if (max_iterations > 0) be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
     for (int r = 0; r < enq; ++r) {
       if (run_ahead && enq == r + 1 && r + 1 < round_limit) { enqueue(r + 1); ++enq; }
-      be.wait(round_ev[r & 1]);
-      const long long* hc = host_counters + 2 * (r % kCounterRing);
-      const long long n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]);
+      long long n_after, n_conv;
+      if (poll) {                                    // (the word is stored by the commit kernel's first lane, right after select has counted)
+        const long long w = await_round_word(r);
+        n_after = w & Publish::kMask24; n_conv = (w >> Publish::kConvShift) & Publish::kMask24;
+      } else {
+        be.wait(round_ev[r & 1]);
+        const long long* hc = host_counters + 2 * (r % kCounterRing);
+        n_after = static_cast<long long>(reinterpret_cast<const int*>(hc)[0]); n_conv = hc[1];
+      }
       stats.agent_iterations += n_before;           // every agent active at the start of a round executes one iLQR iteration
-      stats.converged_solves += hc[1];
+      stats.converged_solves += n_conv;
       stats.batch_iterations++; ++rounds_this_solve;
       if (debug) debug_round();
       be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_before));
@@ -982,9 +997,24 @@ class SolverImpl final : public SolverBase {
       }
       if (enq == r + 1 && r + 1 < round_limit) { enqueue(r + 1); ++enq; }
     }
-    if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);   // drain a round that ran ahead
+    if (poll) { if (enq > rounds_this_solve) be.sync(); }   // a round that ran ahead still publishes its word: drain it before the words are reused
+    else if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);   // drain a round that ran ahead
     last_solve_rounds = rounds_this_solve;
   }
+
+  // the packed word of round r (Publish::pack) in the pinned ring at host_counters[16 ..]: polled, not waited for with an event
+  long long await_round_word(long long r) const {
+    volatile long long* words = host_counters + 16;
+    const long long want = (r + 1) & 0x7FFF;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long long spins = 1;; ++spins) {
+      const long long w = words[r % kCounterRing];
+      if (((w >> Publish::kTagShift) & 0x7FFF) == want) return w;
+      if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+        throw std::runtime_error("the device did not publish a round's counters within 30 s");
+    }
+  }
+  void clear_round_words() const { volatile long long* words = host_counters + 16; for (int q = 0; q < kCounterRing; ++q) words[q] = 0; }
 
 #if !defined(MAS_HOST_EMULATION)
   // ---- fused rounds (mas_fused_hip.hpp): round = [select of the round before + commit + linearisation || Riccati] -> line search ----
@@ -995,7 +1025,7 @@ class SolverImpl final : public SolverBase {
   static constexpr bool kFusedAnalytic = kAllAnalytic && NU == 4;      // no tiles at all: AnalyticSource + one committing wavefront
   static constexpr int kFusedHelpers = kFusedAnalytic ? 1 : ((M::kAnalyticA && M::kAnalyticLxx) ? 2 : 4), kFusedRing = kFusedAnalytic ? 0 : 2;
 #endif
-  bool fused_enabled() const { return switches.fused; }
+  bool fused_enabled() const { return switches.fused && d.N < (1 << 24); }      // (the packed word carries 24-bit agent counts)
   double fused_bytes() const { return sweep_bytes() + backward_bytes(); }
   void launch_fused(const FusedRound& fr, double bytes) {
     using FL = FusedLayout<M, kFusedHelpers, kFusedRing>;
@@ -1015,8 +1045,7 @@ class SolverImpl final : public SolverBase {
     Marks marks[2];
     bool by_slot[2] = {false, false};
     be.zero(fused_error, sizeof(int));
-    volatile long long* words = host_counters + 16;                     // pinned words 16 .. 16 + kRing - 1: one packed word per round (Publish::pack)
-    for (int q = 0; q < kRing; ++q) words[q] = 0;                       // (the device writes nothing here before round 1 of this call)
+    clear_round_words();                                                // pinned words 16 .. 16 + kRing - 1: one packed word per round (Publish::pack); the device writes nothing here before round 1 of this call
     auto enqueue = [&](long long r) {
       Marks& mk = marks[r & 1];
       mk.p0 = be.mark();
@@ -1041,16 +1070,6 @@ class SolverImpl final : public SolverBase {
     // that word: no event between the kernels of consecutive rounds (an event record costs ~6 us of gap per round), and the host
     // knows a whole line search ahead whether round r+1 is needed -- it is, exactly when round r still had active agents -- so
     // nothing is enqueued speculatively and the loop ends with the round that only selects and commits.
-    auto await = [&](long long r) -> long long {
-      const long long want = (r + 1) & 0x7FFF;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (long long spins = 1;; ++spins) {
-        const long long w = words[r % kRing];
-        if (((w >> Publish::kTagShift) & 0x7FFF) == want) return w;
-        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-          throw std::runtime_error("fused round: the device did not publish a round's counters within 30 s");
-      }
-    };
     long long n_before = d.N;             // agents active at the start of the round whose outcome is read next
     live_upper = d.N;
     int rounds_this_solve = 0; bool gave_up = false;
@@ -1059,7 +1078,7 @@ class SolverImpl final : public SolverBase {
       enqueue(1);                         // select(0) + commit: always needed
       be.scale_bytes(marks[0].p0, marks[0].p1, static_cast<double>(d.N));
       for (long long r = 1;; ++r) {       // rounds 0 .. r are enqueued
-        const long long w = await(r);
+        const long long w = await_round_word(r);
         const long long n_after = w & Publish::kMask24, conv = (w >> Publish::kConvShift) & Publish::kMask24;
         if ((w >> Publish::kFlagShift) & 1) { gave_up = true; break; }
         stats.agent_iterations += n_before;           // round r-1 ran one iLQR iteration on every agent active at its start
