@@ -21,7 +21,15 @@ struct BackwardTileLayout {
   // address it would have had if the item list went on -- the residues modulo 16 of one instruction stay a permutation.
   static constexpr int oD = 0, oV = oD + ND, oVx = oV + NX * NX, oAtV = oVx + NX, oBtV = oAtV + NX * NX, oQx = oBtV + NU * NX,
                        oQu = oQx + NX, oQxx = oQu + NU, oQux = oQxx + NX * NX, oQuu = oQux + NU * NX, oL = oQuu + NU * NU, oNegZero = oL + NU * NU,
-                       kUsed = oNegZero + 1, oPad = (kUsed + 15) / 16 * 16, kEnd = oPad + 16;
+                       kOwn = oNegZero + 1;
+  // round 3: [K | k] (NU x (NX+1), column-major) and K^T q_uu (NU x NX), formed once per step by NX+1 lanes (stage A of pass 3) instead
+  // of by every lane of every round.  They live where A^T V and B^T V were: those are dead once pass 2 has read them, and one wavefront's
+  // LDS instructions execute in order (a tile is private to its 16 lanes).  Models whose pass-1 outputs are too small get a region of their own.
+  static constexpr int kGainCols = NU * (NX + 1) + NU * NX;
+  static constexpr bool kGainsAliased = kGainCols + (oAtV & 1) <= NX * NX + NU * NX;
+  static constexpr int oK = kGainsAliased ? oAtV + (oAtV & 1) : kOwn + (kOwn & 1),     // even: a column is one ds_read_b128 for NU = 2
+                       oKtQ = oK + NU * (NX + 1),
+                       kUsed = kGainsAliased ? kOwn : oKtQ + NU * NX, oPad = (kUsed + 15) / 16 * 16, kEnd = oPad + 16;
   // agents of one 32-lane read group (two tiles) kStrideMod doubles apart modulo 32
   static constexpr int kStrideMod = 16;       // measured in round 2 (conflict cycles per wavefront for strides = 16 / 10 / 2 / 0 mod 32: 3,843 / 4,117 / 5,215 / 7,411; launch time within 1 %)
   static constexpr int STRIDE = kEnd + ((kStrideMod - kEnd % 32) % 32 + 32) % 32;
@@ -98,17 +106,17 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   }
 
   // ---- loop-invariant operand addresses of this lane's work items (tile-relative, in doubles)
-  constexpr int W1 = NX * NX + NU * NX + NX + NU, R1 = (W1 + LPA - 1) / LPA;
-  constexpr int W2 = NX * NX + NU * NX + (kLocalQuu ? 0 : NU * NU), R2 = (W2 + LPA - 1) / LPA;
-  int p1[R1], q1[R1], b1[R1], o1[R1];              // pass 1: out = [bias +] sum_k T[p+k] * T[q+k]
+  // q_x and q_u (ilqr.hpp:117: tile and v_x only) are dealt with pass 2's items, not pass 1's: nothing before pass 3 reads them, and
+  // for NX = 6, NU = 2 the passes then take 3 + 4 rounds of 16 lanes (48 + 60 items) instead of 4 + 4 (56 + 52)
+  constexpr int W1 = NX * NX + NU * NX, R1 = (W1 + LPA - 1) / LPA;
+  constexpr int W2q = NX * NX + NU * NX + (kLocalQuu ? 0 : NU * NU), W2 = W2q + NX + NU, R2 = (W2 + LPA - 1) / LPA;
+  int p1[R1], q1[R1], o1[R1];                      // pass 1: out = sum_k T[p+k] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R1; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, qa = 0, ba = TL::oNegZero, oa = TL::pad_at(TL::oAtV + w);     // idle lanes of the last round: own pad slot
+    int pa = 0, qa = 0, oa = TL::pad_at(TL::oAtV + w);     // idle lanes of the last round: own pad slot
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
-    else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
-    else if (w < NX * NX + NU * NX + NX) { const int i = w - NX * NX - NU * NX; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }
-    else if (w < W1) { const int i = w - NX * NX - NU * NX - NX; pa = TL::oD + L::oB + i * NX; qa = TL::oVx; ba = TL::oD + L::oLu + i; oa = TL::oQu + i; }
-    p1[r] = pa; q1[r] = qa; b1[r] = ba; o1[r] = oa;
+    else if (w < W1) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
+    p1[r] = pa; q1[r] = qa; o1[r] = oa;
   }
   int p2[R2], ps2[R2], q2[R2], b2[R2], o2[R2];     // pass 2: out = bias + sum_k T[p + k*ps] * T[q+k]
   MAS_UNROLL for (int r = 0; r < R2; ++r) {
@@ -116,7 +124,9 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     int pa = 0, ps = 1, qa = 0, ba = 0, oa = TL::pad_at(TL::oQxx + w);
     if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oAtV + i; ps = NX; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLxx + w; oa = TL::oQxx + w; }
     else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLux + e; oa = TL::oQux + e; }
-    else if (w < W2) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
+    else if (w < W2q) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
+    else if (w < W2q + NX) { const int i = w - W2q; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }            // q_x = l_x + A^T v_x
+    else if (w < W2) { const int i = w - W2q - NX; pa = TL::oD + L::oB + i * NX; qa = TL::oVx; ba = TL::oD + L::oLu + i; oa = TL::oQu + i; }               // q_u = l_u + B^T v_x
     p2[r] = pa; ps2[r] = ps; q2[r] = qa; b2[r] = ba; o2[r] = oa;
   }
 
@@ -150,12 +160,43 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     MAS_UNROLL for (int q = 0; q < LL - 1; ++q) { rung_add[q] = (q < rung_lane) ? reg : -0.0; reg *= 10.0; }
   }
   // gain stores: uniform per-step base pointers + loop-invariant 32-bit byte offsets (row * Np + agent) * 8
-  constexpr int RMX = (NX * NX + LPA - 1) / LPA;
-  unsigned goff[NU], koff[RMX][NU];                  // k rows; this lane's gain column (rows i*NU + m) per round
+  unsigned goff[NU], koff[NU];                       // k rows; gain column `lane` (rows lane*NU + m) of the stage-A lanes
   MAS_UNROLL for (int m = 0; m < NU; ++m) goff[m] = static_cast<unsigned>((static_cast<size_t>(m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
-  MAS_UNROLL for (int r = 0; r < RMX; ++r) {
-    const int w = lane + r * LPA, i = (w < NX * NX) ? (w % NX) : 0;
-    MAS_UNROLL for (int m = 0; m < NU; ++m) koff[r][m] = static_cast<unsigned>((static_cast<size_t>(i * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  MAS_UNROLL for (int m = 0; m < NU; ++m) koff[m] = static_cast<unsigned>((static_cast<size_t>((lane < NX ? lane : 0) * NU + m) * d.Np + static_cast<size_t>(a)) * sizeof(double));
+  // ---- pass 3, stage A: column c = lane of [q_ux | q_u] in, of [K | k] and [K | k]^T q_uu out (lanes beyond NX repeat column 0 into their pad slots)
+  static_assert(NX + 1 <= LPA, "one lane per column of [K | k]");
+  const int a_qc = (lane < NX) ? TL::oQux + lane * NU : (lane == NX) ? TL::oQu : TL::oQux;
+  int w_kc[NU], w_tc[NU];                            // (element by element: a pad slot is ONE double; column NX of K^T q_uu is not used)
+  MAS_UNROLL for (int m = 0; m < NU; ++m) {
+    w_kc[m] = (lane <= NX) ? TL::oK + lane * NU + m : TL::pad_at(TL::oK + lane * NU + m);
+    w_tc[m] = (lane < NX) ? TL::oKtQ + lane * NU + m : TL::pad_at(TL::oKtQ + lane * NU + m);
+  }
+  // ---- pass 3, stage B: items = the NX (NX + 1) / 2 pairs of mirrored v_xx entries (i >= j, column by column) + the NX entries of v_x
+  // (column j = NX of the extended matrices).  An item forms BOTH entries of its pair -- they share all their operands -- so that 36 + 6
+  // results take 27 items = 2 rounds of 16 lanes for NX = 6 where one entry per lane took 3 (each of them forming its mirror as well).
+  constexpr int NPAIR = NX * (NX + 1) / 2, W3 = NPAIR + NX, R3 = (W3 + LPA - 1) / LPA;
+  static_assert(R3 <= 32, "is_vx bit field");
+  int a_Ki[R3], a_Kj[R3], a_qi[R3], a_qj[R3], a_ti[R3], a_tj[R3], a_own[R3], a_mir[R3], out_lo[R3], out_up[R3];
+  unsigned is_vx = 0u;
+  MAS_UNROLL for (int r = 0; r < R3; ++r) {
+    const int w = lane + r * LPA;
+    int i = 0, j = 0, rem = w;
+    bool found = false;
+    MAS_UNROLL for (int c = 0; c < NX; ++c) {
+      if (!found && rem < NX - c) { j = c; i = c + rem; found = true; }
+      if (!found) rem -= NX - c;
+    }
+    const bool vx = !found && rem < NX;               // rem = w - NPAIR here
+    if (vx) { i = rem; j = NX; }
+    if (!found && !vx) { i = 0; j = 0; }              // idle lane of the last round: reads item 0's operands, writes its pad slots
+    a_Ki[r] = TL::oK + i * NU; a_Kj[r] = TL::oK + j * NU;
+    a_qi[r] = TL::oQux + i * NU; a_qj[r] = (j < NX) ? TL::oQux + j * NU : TL::oQu;
+    a_ti[r] = TL::oKtQ + i * NU; a_tj[r] = TL::oKtQ + (j < NX ? j : 0) * NU;
+    a_own[r] = (j < NX) ? TL::oQxx + j * NX + i : TL::oQx + i;
+    a_mir[r] = (j < NX) ? TL::oQxx + i * NX + j : TL::oQx + i;
+    out_lo[r] = (valid && found) ? TL::oV + j * NX + i : (valid && vx) ? TL::oVx + i : TL::pad_at(TL::oV + w);
+    out_up[r] = (valid && found && i != j) ? TL::oV + i * NX + j : TL::pad_at(TL::oV + w + 8);
+    if (vx) is_vx |= 1u << r;
   }
   double* kff_t = kff + static_cast<size_t>(d.T - 1) * NU * d.Np;
   double* Kfb_t = Kfb + static_cast<size_t>(d.T - 1) * NU * NX * d.Np;
@@ -170,7 +211,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     if (t > 0) tiles_t -= step_doubles;              // uniform; at t == 0 the (unused) prefetch re-reads step 0
     MAS_UNROLL for (int c = 0; c < NCH; ++c) MAS_OPAQUE32(fetch_off[c]);
     MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(goff[m]);
-    MAS_UNROLL for (int r = 0; r < RMX; ++r) { MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(koff[r][m]); }
+    MAS_UNROLL for (int m = 0; m < NU; ++m) MAS_OPAQUE32(koff[m]);
     fetch();
     wave_sync();
 
@@ -178,13 +219,12 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     {
       double res[R1];
       MAS_UNROLL for (int r = 0; r < R1; ++r) {
-        const double s = sum_terms<NX>([&](int k) { return T[p1[r] + k] * T[q1[r] + k]; });
-        res[r] = T[b1[r]] + s;                                        // items without a bias term add -0.0
+        res[r] = sum_terms<NX>([&](int k) { return T[p1[r] + k] * T[q1[r] + k]; });
       }
       MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // idle lanes write their own pad slot
     }
     wave_sync();
-    double quu[NU * NU], qu[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU];
+    double quu[NU * NU], Lfac[NU * NU], ninv[NU * NU];
     if constexpr (kLocalQuu) {                                        // q_uu = l_uu + (B^T V) B, :119, every lane for itself
       MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
         const int i = e % NU, j = e / NU;
@@ -320,63 +360,48 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
           MAS_UNROLL for (int i = 0; i < NU * NU; ++i) Lfac[i] = T[TL::oL + i];
         }
       }
-      MAS_UNROLL for (int i = 0; i < NU; ++i) qu[i] = T[TL::oQu + i];
       llt_solve_identity<NU>(Lfac, ninv);                           // Quu_reg^-1, :183
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) ninv[i] = -ninv[i];
-      MAS_UNROLL for (int m = 0; m < NU; ++m) kf[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qu[q]; });   // k = -Quu^-1 q_u, :185
-      // gain stores are unconditional straight-line code: every lane of an agent holds the same k (and every lane
-      // with the same i the same K column), so the duplicates write identical bits to identical addresses, and an
-      // idle slot writes into the unused gain rows of its retired agent: no divergent branch, no exec juggling.
-      MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], kf[m]);
-
-      constexpr int RM = (NX * NX + LPA - 1) / LPA;                  // rounds over the v_xx entries
-      MAS_UNROLL for (int r = 0; r < RM; ++r) {
-        const int w = lane + r * LPA;
-        const bool live = valid && (w < NX * NX);
-        const int i = (w < NX * NX) ? (w % NX) : 0;
-        const int j = (w < NX * NX) ? (w / NX) : 0;
-        double quxi[NU], quxj[NU], Ki[NU], Kj[NU], ktqi[NU], ktqj[NU];
-        MAS_UNROLL for (int m = 0; m < NU; ++m) { quxi[m] = T[TL::oQux + i * NU + m]; quxj[m] = T[TL::oQux + j * NU + m]; }
-        const double qxx_own = T[TL::oQxx + j * NX + i], qxx_mir = T[TL::oQxx + i * NX + j], qx_i = T[TL::oQx + i];
-        MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // columns i and j of K = -Quu^-1 q_ux, :186
-          Ki[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxi[q]; });
-          Kj[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * quxj[q]; });
+      // ---- stage A: lane c <= NX forms column c of [K | k] = -Quu^-1 [q_ux | q_u] (:185-186) and of its product with the
+      // unregularised q_uu; the gains leave for HBM from here (K by lanes 0..NX-1, k by lane NX), once per step
+      {
+        double qc[NU], Kc[NU], tc[NU];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) qc[m] = T[a_qc + m];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) Kc[m] = sum_terms<NU>([&](int q) { return ninv[q * NU + m] * qc[q]; });
+        MAS_UNROLL for (int m = 0; m < NU; ++m) tc[m] = sum_terms<NU>([&](int q) { return Kc[q] * quu[m * NU + q]; });
+        MAS_UNROLL for (int m = 0; m < NU; ++m) { T[w_kc[m]] = Kc[m]; T[w_tc[m]] = tc[m]; }
+        if (lane < NX) { MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[m], Kc[m]); }
+        if (lane == NX) { MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(kff_t, goff[m], Kc[m]); }
+      }
+      wave_sync();
+      // ---- stage B: v_xx and v_x (:188-192), one item per pair of mirrored entries (i >= j) and one per v_x entry
+      MAS_UNROLL for (int r = 0; r < R3; ++r) {
+        double Ki[NU], Kj[NU], qi[NU], qj[NU], ti[NU], tj[NU];
+        MAS_UNROLL for (int m = 0; m < NU; ++m) {
+          Ki[m] = T[a_Ki[r] + m]; Kj[m] = T[a_Kj[r] + m]; qi[m] = T[a_qi[r] + m]; qj[m] = T[a_qj[r] + m]; ti[m] = T[a_ti[r] + m]; tj[m] = T[a_tj[r] + m];
         }
-        MAS_UNROLL for (int m = 0; m < NU; ++m) {                   // rows i and j of K^T q_uu (unregularised)
-          ktqi[m] = sum_terms<NU>([&](int q) { return Ki[q] * quu[m * NU + q]; });
-          ktqj[m] = sum_terms<NU>([&](int q) { return Kj[q] * quu[m * NU + q]; });
-        }
-        // own entry (i,j) and mirror entry (j,i) of v_xx, :190-191
+        const double q_own = T[a_own[r]], q_mir = T[a_mir[r]];
+        // entry (i,j) -- for a v_x item: q_x[i] + K_i.q_u + q_ux,i.k + (K^T q_uu)_i.k, the same expression with column NX of [K | k], [q_ux | q_u]
         double s, own, mir;
-        s = sum_terms<NU>([&](int m) { return Ki[m] * quxj[m]; });
-        own = qxx_own + s;
-        s = sum_terms<NU>([&](int m) { return quxi[m] * Kj[m]; });
+        s = sum_terms<NU>([&](int m) { return Ki[m] * qj[m]; });
+        own = q_own + s;
+        s = sum_terms<NU>([&](int m) { return qi[m] * Kj[m]; });
         own = own + s;
-        s = sum_terms<NU>([&](int m) { return ktqi[m] * Kj[m]; });
+        s = sum_terms<NU>([&](int m) { return ti[m] * Kj[m]; });
         own = own + s;
-        s = sum_terms<NU>([&](int m) { return Kj[m] * quxi[m]; });
-        mir = qxx_mir + s;
-        s = sum_terms<NU>([&](int m) { return quxj[m] * Ki[m]; });
+        // entry (j,i)
+        s = sum_terms<NU>([&](int m) { return Kj[m] * qi[m]; });
+        mir = q_mir + s;
+        s = sum_terms<NU>([&](int m) { return qj[m] * Ki[m]; });
         mir = mir + s;
-        s = sum_terms<NU>([&](int m) { return ktqj[m] * Ki[m]; });
+        s = sum_terms<NU>([&](int m) { return tj[m] * Ki[m]; });
         mir = mir + s;
-        // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: a lower or diagonal
-        // entry averages the old values, an upper entry sees its (already rewritten) mirror
-        const double sym = (i >= j) ? 0.5 * (own + mir) : 0.5 * (own + 0.5 * (mir + own));
-        T[live ? (TL::oV + w) : TL::pad_at(TL::oV + w)] = sym;
-        // the lanes of the first tile column (j == 0) also own gain column i and v_x entry i, :186,188-189
-        {
-          double vxi;
-          s = sum_terms<NU>([&](int m) { return Ki[m] * qu[m]; });
-          vxi = qx_i + s;
-          s = sum_terms<NU>([&](int m) { return quxi[m] * kf[m]; });
-          vxi = vxi + s;
-          s = sum_terms<NU>([&](int m) { return ktqi[m] * kf[m]; });
-          vxi = vxi + s;
-          const bool owner = live && j == 0;
-          T[owner ? (TL::oVx + i) : TL::pad_at(TL::oVx + w)] = vxi;
-          MAS_UNROLL for (int m = 0; m < NU; ++m) st_off(Kfb_t, koff[r][m], Ki[m]);
-        }
+        // v_xx = 0.5 (v_xx + v_xx^T) in the reference's aliased in-place order, :192: the lower (or diagonal) entry averages the old
+        // values, the upper entry sees its already rewritten mirror
+        const double lower = 0.5 * (own + mir);
+        const double upper = 0.5 * (mir + lower);
+        T[out_lo[r]] = (is_vx >> r & 1u) ? own : lower;
+        T[out_up[r]] = upper;
       }
     }
     // the barrier after the next publish orders these writes before pass 1 reads them
