@@ -38,10 +38,11 @@ __device__ __forceinline__ void llt_solve_identity_by_columns(const double* Lm, 
   }
   gather_inverse<N>(o, Inv, std::make_integer_sequence<int, N * N>{});
 }
-// q_uu entries from the pass-2 results of the LDS-tile kernel: entry e is item W0 + e, formed in round (W0 + e) / 16 by lane (W0 + e) % 16
-template <int W0, int R2, int... E>
-__device__ __forceinline__ void tile_gather_quu(const double (&res)[R2], double* quu, std::integer_sequence<int, E...>) {
-  ((quu[E] = row_bcast<(W0 + E) % 16>(res[(W0 + E) / 16])), ...);
+// q_uu entries from the pass-2 results of the LDS-tile kernel: entry e = j*NU + i is result (i % 2) + 2 (j % 2) of the 2 x 2 block
+// (i / 2, j / 2), item W0 + (j / 2) * UP + i / 2, formed in round item / 16 by lane item % 16
+template <int NU, int W0, int UP, int R2, int... E>
+__device__ __forceinline__ void tile_gather_quu(const double (&res)[R2][4], double* quu, std::integer_sequence<int, E...>) {
+  ((quu[E] = row_bcast<(W0 + ((E / NU) / 2) * UP + (E % NU) / 2) % 16>(res[(W0 + ((E / NU) / 2) * UP + (E % NU) / 2) / 16][((E % NU) % 2) + 2 * ((E / NU) % 2)])), ...);
 }
 // sum of N terms in index order, starting FROM THE FIRST TERM -- as Eigen's redux does for the reference's small products.  The
 // CPU oracle and the one-lane bodies start from +0.0 (s = 0.0; s += term_k); the two agree in every bit except that an

@@ -56,11 +56,8 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   constexpr int APW = 64 / LPA;                     // agents per wavefront (LPA lanes per agent)
   constexpr int LL = 16;                            // ladder width: rungs tried at once (lanes beyond LL repeat rung lane % LL)
   static_assert(LPA >= LL && 64 % LPA == 0, "lanes per agent");
-  // kLocalQuu (experiment, off): every lane forms q_uu itself right after pass 1, so that the LLT / ladder chain starts one
-  // LDS round trip earlier and pass 2 runs in its shadow.  Measured on C3: 142 us per launch against 132 us -- the 36 extra
-  // FP64 instructions per lane cost more than the round trip saves; the kernel is bound by dependent-issue latency
-  // (7 cycles per dependent FP64 instruction, ~255 of them per step), not by LDS.
-  constexpr bool kLocalQuu = false;
+  // (Measured and rejected in round 2: every lane forming q_uu itself right after pass 1 so that the LLT / ladder chain starts one LDS
+  // round trip earlier -- C3 142 us per launch against 132: the 36 extra FP64 instructions per lane cost more than the round trip saves.)
   __shared__ double lds[WPB * APW * TL::STRIDE];
   __shared__ unsigned blk_field[2][WPB > 1 ? WPB : 1];   // rung masks of the workgroup's wavefronts, double-buffered by agreement parity
   __shared__ unsigned blk_agreed[2];
@@ -106,28 +103,50 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   }
 
   // ---- loop-invariant operand addresses of this lane's work items (tile-relative, in doubles)
-  // q_x and q_u (ilqr.hpp:117: tile and v_x only) are dealt with pass 2's items, not pass 1's: nothing before pass 3 reads them, and
-  // for NX = 6, NU = 2 the passes then take 3 + 4 rounds of 16 lanes (48 + 60 items) instead of 4 + 4 (56 + 52)
-  constexpr int W1 = NX * NX + NU * NX, R1 = (W1 + LPA - 1) / LPA;
-  constexpr int W2q = NX * NX + NU * NX + (kLocalQuu ? 0 : NU * NU), W2 = W2q + NX + NU, R2 = (W2 + LPA - 1) / LPA;
-  int p1[R1], q1[R1], o1[R1];                      // pass 1: out = sum_k T[p+k] * T[q+k]
+  // Passes 1 and 2 are length-NX dot products row . column; an item is a 2 x 2 BLOCK of them -- two adjacent row vectors against two
+  // adjacent column vectors, 4 NX doubles read for four results where one result per item read 2 NX each.  (Round 3: with two
+  // wavefronts per SIMD -- 8192 bicycle6 agents -- the launch follows the CU's LDS bandwidth, not the instruction count.)
+  //   pass 1   rows: the NX + NU vectors A_i, B_i of the tile (contiguous, NX apart);  columns: V_0 .. V_{NX-1}, v_x (contiguous, NX apart)
+  //            -> A^T V, B^T V, and in the v_x column q_x = l_x + A^T v_x, q_u = l_u + B^T v_x (:115-117).  For NX = 6, NU = 2: 4 x 4 = 16 items.
+  //   pass 2   rows: those of A^T V (1 apart, stride NX) or of B^T V (1 apart, stride NU);  columns: A_j or B_j
+  //            -> q_xx, q_ux, q_uu = l + row . column (:117-119).  9 + 3 + 1 = 13 items.
+  // An odd count's last pair overlaps its neighbour (columns of pass 1) or runs one vector past its group (the rest): such a result is
+  // formed from finite tile contents and written to a pad slot.
+  constexpr int RP1 = (NX + NU + 1) / 2, CN1 = NX + 1, CP1 = (CN1 + 1) / 2, W1 = RP1 * CP1, R1 = (W1 + LPA - 1) / LPA;
+  int p1[R1], q1[R1], b1[R1][2], o1[R1][4];       // results (r0,c0) (r1,c0) (r0,c1) (r1,c1); only column c1 can be v_x, i.e. carry a bias
   MAS_UNROLL for (int r = 0; r < R1; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, qa = 0, oa = TL::pad_at(TL::oAtV + w);     // idle lanes of the last round: own pad slot
-    if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oD + L::oA + i * NX; qa = TL::oV + j * NX; oa = TL::oAtV + w; }
-    else if (w < W1) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oD + L::oB + i * NX; qa = TL::oV + j * NX; oa = TL::oBtV + e; }
-    p1[r] = pa; q1[r] = qa; o1[r] = oa;
+    const bool item = w < W1;
+    const int rp = item ? w % RP1 : 0, cp = item ? w / RP1 : 0;
+    const int r0 = 2 * rp, c0 = (2 * cp + 1 < CN1) ? 2 * cp : CN1 - 2;
+    p1[r] = TL::oD + L::oA + r0 * NX; q1[r] = TL::oV + c0 * NX;
+    MAS_UNROLL for (int k = 0; k < 4; ++k) {
+      const int rr = r0 + (k & 1), cc = c0 + (k >> 1);
+      const bool fresh = item && rr < NX + NU && cc < CN1 && !(cc == c0 && c0 != 2 * cp);    // (the overlapping column was its neighbour's c1)
+      const int dst = (cc < NX) ? (rr < NX ? TL::oAtV + cc * NX + rr : TL::oBtV + cc * NU + (rr - NX)) : (rr < NX ? TL::oQx + rr : TL::oQu + (rr - NX));
+      o1[r][k] = fresh ? dst : TL::pad_at(w + 4 * k);
+      if (k >> 1) b1[r][k & 1] = (fresh && cc == NX) ? TL::oD + L::oLx + rr : TL::oNegZero;     // (l_u follows l_x in the tile)
+    }
   }
-  int p2[R2], ps2[R2], q2[R2], b2[R2], o2[R2];     // pass 2: out = bias + sum_k T[p + k*ps] * T[q+k]
+  static_assert(L::oLu == L::oLx + NX && L::oB == L::oA + NX * NX, "tile layout: B after A, l_u after l_x");
+  constexpr int XP = (NX + 1) / 2, UP = (NU + 1) / 2, W2xx = XP * XP, W2ux = W2xx + UP * XP, W2 = W2ux + UP * UP, R2 = (W2 + LPA - 1) / LPA;
+  int p2[R2], ps2[R2], q2[R2], b2[R2][4], o2[R2][4];   // results (r0,c0) (r1,c0) (r0,c1) (r1,c1), each = T[b] + sum_k T[p + (0|1) + k*ps] * T[q + (0|NX) + k]
   MAS_UNROLL for (int r = 0; r < R2; ++r) {
     const int w = lane + r * LPA;
-    int pa = 0, ps = 1, qa = 0, ba = 0, oa = TL::pad_at(TL::oQxx + w);
-    if (w < NX * NX) { const int i = w % NX, j = w / NX; pa = TL::oAtV + i; ps = NX; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLxx + w; oa = TL::oQxx + w; }
-    else if (w < NX * NX + NU * NX) { const int e = w - NX * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oA + j * NX; ba = TL::oD + L::oLux + e; oa = TL::oQux + e; }
-    else if (w < W2q) { const int e = w - NX * NX - NU * NX, i = e % NU, j = e / NU; pa = TL::oBtV + i; ps = NU; qa = TL::oD + L::oB + j * NX; ba = TL::oD + L::oLuu + e; oa = TL::oQuu + e; }
-    else if (w < W2q + NX) { const int i = w - W2q; pa = TL::oD + L::oA + i * NX; qa = TL::oVx; ba = TL::oD + L::oLx + i; oa = TL::oQx + i; }            // q_x = l_x + A^T v_x
-    else if (w < W2) { const int i = w - W2q - NX; pa = TL::oD + L::oB + i * NX; qa = TL::oVx; ba = TL::oD + L::oLu + i; oa = TL::oQu + i; }               // q_u = l_u + B^T v_x
-    p2[r] = pa; ps2[r] = ps; q2[r] = qa; b2[r] = ba; o2[r] = oa;
+    const bool item = w < W2;
+    const int kind = !item ? 0 : (w < W2xx) ? 0 : (w < W2ux) ? 1 : 2;                 // q_xx / q_ux / q_uu
+    const int e = (kind == 0) ? (item ? w : 0) : (kind == 1) ? w - W2xx : w - W2ux;
+    const int rows = (kind == 0) ? NX : NU, cols = (kind == 2) ? NU : NX, rpn = (kind == 0) ? XP : UP;
+    const int r0 = 2 * (e % rpn), c0 = 2 * (e / rpn);
+    p2[r] = ((kind == 0) ? TL::oAtV : TL::oBtV) + r0; ps2[r] = rows;
+    q2[r] = TL::oD + ((kind == 2) ? L::oB : L::oA) + c0 * NX;
+    const int out0 = (kind == 0) ? TL::oQxx : (kind == 1) ? TL::oQux : TL::oQuu, bias0 = TL::oD + ((kind == 0) ? L::oLxx : (kind == 1) ? L::oLux : L::oLuu);
+    MAS_UNROLL for (int k = 0; k < 4; ++k) {
+      const int rr = r0 + (k & 1), cc = c0 + (k >> 1);
+      const bool fresh = item && rr < rows && cc < cols;
+      o2[r][k] = fresh ? out0 + cc * rows + rr : TL::pad_at(w + 4 * k);
+      b2[r][k] = fresh ? bias0 + cc * rows + rr : TL::oNegZero;
+    }
   }
 
   // software pipeline: the tiles of step t-1 travel HBM -> registers while step t is computed.  Every lane works for
@@ -215,39 +234,40 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
     fetch();
     wave_sync();
 
-    // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
+    // ---- pass 1 (ilqr.hpp:115-117: A^T V, B^T V, q_x, q_u)
     {
-      double res[R1];
+      double res[R1][4];
       MAS_UNROLL for (int r = 0; r < R1; ++r) {
-        res[r] = sum_terms<NX>([&](int k) { return T[p1[r] + k] * T[q1[r] + k]; });
+        double pr0[NX], pr1[NX], qc0[NX], qc1[NX];
+        MAS_UNROLL for (int k = 0; k < NX; ++k) { pr0[k] = T[p1[r] + k]; pr1[k] = T[p1[r] + NX + k]; qc0[k] = T[q1[r] + k]; qc1[k] = T[q1[r] + NX + k]; }
+        res[r][0] = sum_terms<NX>([&](int k) { return pr0[k] * qc0[k]; });
+        res[r][1] = sum_terms<NX>([&](int k) { return pr1[k] * qc0[k]; });
+        const double s2 = sum_terms<NX>([&](int k) { return pr0[k] * qc1[k]; }), s3 = sum_terms<NX>([&](int k) { return pr1[k] * qc1[k]; });
+        res[r][2] = T[b1[r][0]] + s2;                                   // l_x / l_u in the v_x column, -0.0 (adds nothing, keeps every bit) elsewhere
+        res[r][3] = T[b1[r][1]] + s3;
       }
-      MAS_UNROLL for (int r = 0; r < R1; ++r) T[o1[r]] = res[r];      // idle lanes write their own pad slot
+      MAS_UNROLL for (int r = 0; r < R1; ++r) { MAS_UNROLL for (int k = 0; k < 4; ++k) T[o1[r][k]] = res[r][k]; }      // idle results: own pad slots
     }
     wave_sync();
     double quu[NU * NU], Lfac[NU * NU], ninv[NU * NU];
-    if constexpr (kLocalQuu) {                                        // q_uu = l_uu + (B^T V) B, :119, every lane for itself
-      MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {
-        const int i = e % NU, j = e / NU;
-        double s = 0.0;
-        MAS_UNROLL for (int k = 0; k < NX; ++k) s += T[TL::oBtV + i + k * NU] * T[TL::oD + L::oB + j * NX + k];
-        quu[e] = T[TL::oD + L::oLuu + e] + s;
-      }
-    }
-    // ---- pass 2 (second factors of ilqr.hpp:117-119)
+    // ---- pass 2 (ilqr.hpp:117-119: q_xx, q_ux, q_uu)
     {
-      double res[R2];
+      double res[R2][4];
       MAS_UNROLL for (int r = 0; r < R2; ++r) {
-        const double s = sum_terms<NX>([&](int k) { return T[p2[r] + k * ps2[r]] * T[q2[r] + k]; });
-        res[r] = T[b2[r]] + s;
+        double pr0[NX], pr1[NX], qc0[NX], qc1[NX];
+        MAS_UNROLL for (int k = 0; k < NX; ++k) { pr0[k] = T[p2[r] + k * ps2[r]]; pr1[k] = T[p2[r] + k * ps2[r] + 1]; qc0[k] = T[q2[r] + k]; qc1[k] = T[q2[r] + NX + k]; }
+        const double s0 = sum_terms<NX>([&](int k) { return pr0[k] * qc0[k]; }), s1 = sum_terms<NX>([&](int k) { return pr1[k] * qc0[k]; });
+        const double s2 = sum_terms<NX>([&](int k) { return pr0[k] * qc1[k]; }), s3 = sum_terms<NX>([&](int k) { return pr1[k] * qc1[k]; });
+        res[r][0] = T[b2[r][0]] + s0; res[r][1] = T[b2[r][1]] + s1; res[r][2] = T[b2[r][2]] + s2; res[r][3] = T[b2[r][3]] + s3;
       }
-      MAS_UNROLL for (int r = 0; r < R2; ++r) T[o2[r]] = res[r];
-      if constexpr (!kLocalQuu && LPA == 16) {
-        // q_uu straight from the lanes that formed it (item NX^2 + NU NX + e sits in round (..) / 16 on lane (..) % 16, and an agent's 16
-        // lanes are one DPP row): the LLT / ladder chain starts without waiting for the LDS round trip of the other pass-2 results
-        tile_gather_quu<NX * NX + NU * NX, R2>(res, quu, std::make_integer_sequence<int, NU * NU>{});
+      MAS_UNROLL for (int r = 0; r < R2; ++r) { MAS_UNROLL for (int k = 0; k < 4; ++k) T[o2[r][k]] = res[r][k]; }
+      if constexpr (LPA == 16) {
+        // q_uu straight from the lanes that formed it (an agent's 16 lanes are one DPP row): the LLT / ladder chain starts without
+        // waiting for the LDS round trip of the other pass-2 results
+        tile_gather_quu<NU, W2ux, UP>(res, quu, std::make_integer_sequence<int, NU * NU>{});
       }
     }
-    if constexpr (!kLocalQuu && LPA != 16) {
+    if constexpr (LPA != 16) {
       wave_sync();
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
     }
