@@ -136,7 +136,7 @@ int mas_hip_check_params(const mas_hip_solver*);
  * Several launches exist in more than one BIT-IDENTICAL form (e.g. the two-kernel fused round against the five-kernel one, the
  * one-lane against the four-lane line search); the defaults are the measured best.  The parity tests hold the forms against each
  * other through this entry point.  Keys: "fused" (0/1), "forward_quad_max" (live agents), "backward_tile" (0/1),
- * "backward_list" (0/1), "central_pipeline" (0/1), "central_one_xcd" (0/1), "force_single_workgroup_central" (0/1),
+ * "backward_list" (0/1), "backward_wide_max" / "backward_wave_max" (live agents up to which the six-state backward pass uses 32 / 64 lanes per agent), "central_pipeline" (0/1), "central_one_xcd" (0/1), "force_single_workgroup_central" (0/1),
  * "central_combine" (0/1), "central_wpb" (1, 2, 4, 8, 16).  Unknown key or value: MAS_HIP_ERR_INVALID.  Results never depend on them. */
 int mas_hip_set_option(mas_hip_solver*, const char* key, int64_t value);
 

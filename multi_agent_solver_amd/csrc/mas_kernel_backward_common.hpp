@@ -8,6 +8,10 @@
 
 namespace mas {
 
+__device__ __forceinline__ double lane_read(double v, int src_lane) {      // v of lane src_lane of the wavefront (ds_bpermute, no memory)
+  const int lo32 = __builtin_amdgcn_ds_bpermute(src_lane * 4, __double2loint(v)), hi32 = __builtin_amdgcn_ds_bpermute(src_lane * 4, __double2hiint(v));
+  return __hiloint2double(hi32, lo32);
+}
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {      // lane SRC of the 16-lane row -> every lane of the row
   return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + SRC, 0xF, 0xF, true));
@@ -38,11 +42,19 @@ __device__ __forceinline__ void llt_solve_identity_by_columns(const double* Lm, 
   }
   gather_inverse<N>(o, Inv, std::make_integer_sequence<int, N * N>{});
 }
-// q_uu entries from the pass-2 results of the LDS-tile kernel: entry e = j*NU + i is result (i % 2) + 2 (j % 2) of the 2 x 2 block
-// (i / 2, j / 2), item W0 + (j / 2) * UP + i / 2, formed in round item / 16 by lane item % 16
-template <int NU, int W0, int UP, int R2, int... E>
-__device__ __forceinline__ void tile_gather_quu(const double (&res)[R2][4], double* quu, std::integer_sequence<int, E...>) {
-  ((quu[E] = row_bcast<(W0 + ((E / NU) / 2) * UP + (E % NU) / 2) % 16>(res[(W0 + ((E / NU) / 2) * UP + (E % NU) / 2) / 16][((E % NU) % 2) + 2 * ((E / NU) % 2)])), ...);
+// q_uu entries from the pass-2 results of the LDS-tile kernel (items = BR x BC blocks of results, LPA lanes per agent): entry
+// e = j*NU + i is result (i % BR) + BR (j % BC) of block (i / BR, j / BC), item W0 + (j / BC) * UP + i / BR, formed in round
+// item / LPA by lane item % LPA of the agent.  16 lanes per agent are one DPP row (row broadcast); wider agents read the lane
+// through ds_bpermute (agent_lane0 = first lane of the agent in the wavefront).
+template <int NU, int W0, int UP, int BR, int BC, int LPA, int R2, int... E>
+__device__ __forceinline__ void tile_gather_quu(const double (&res)[R2][BR * BC], double* quu, int agent_lane0, std::integer_sequence<int, E...>) {
+  if constexpr (LPA == 16) {
+    (void)agent_lane0;
+    ((quu[E] = row_bcast<(W0 + ((E / NU) / BC) * UP + (E % NU) / BR) % 16>(res[(W0 + ((E / NU) / BC) * UP + (E % NU) / BR) / 16][((E % NU) % BR) + BR * ((E / NU) % BC)])), ...);
+  } else {
+    ((quu[E] = lane_read(res[(W0 + ((E / NU) / BC) * UP + (E % NU) / BR) / LPA][((E % NU) % BR) + BR * ((E / NU) % BC)],
+                         agent_lane0 + (W0 + ((E / NU) / BC) * UP + (E % NU) / BR) % LPA)), ...);
+  }
 }
 // sum of N terms in index order, starting FROM THE FIRST TERM -- as Eigen's redux does for the reference's small products.  The
 // CPU oracle and the one-lane bodies start from +0.0 (s = 0.0; s += term_k); the two agree in every bit except that an

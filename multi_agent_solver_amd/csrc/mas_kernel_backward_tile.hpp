@@ -103,46 +103,50 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   }
 
   // ---- loop-invariant operand addresses of this lane's work items (tile-relative, in doubles)
-  // Passes 1 and 2 are length-NX dot products row . column; an item is a 2 x 2 BLOCK of them -- two adjacent row vectors against two
-  // adjacent column vectors, 4 NX doubles read for four results where one result per item read 2 NX each.  (Round 3: with two
-  // wavefronts per SIMD -- 8192 bicycle6 agents -- the launch follows the CU's LDS bandwidth, not the instruction count.)
+  // Passes 1 and 2 are length-NX dot products row . column; an item is a BR x BC BLOCK of them -- adjacent row vectors against
+  // adjacent column vectors.  16 lanes per agent: 2 x 2, 4 NX doubles read for four results where one result per item read 2 NX each
+  // (round 3: with two wavefronts per SIMD -- 8192 bicycle6 agents -- the launch follows the CU's LDS bandwidth, not the instruction
+  // count).  32 lanes per agent (the tail rounds' form, where a launch is as long as ONE wavefront's chain of instructions): 2 x 1,
+  // half the instructions per lane; 64 lanes: 1 x 1.
   //   pass 1   rows: the NX + NU vectors A_i, B_i of the tile (contiguous, NX apart);  columns: V_0 .. V_{NX-1}, v_x (contiguous, NX apart)
-  //            -> A^T V, B^T V, and in the v_x column q_x = l_x + A^T v_x, q_u = l_u + B^T v_x (:115-117).  For NX = 6, NU = 2: 4 x 4 = 16 items.
+  //            -> A^T V, B^T V, and in the v_x column q_x = l_x + A^T v_x, q_u = l_u + B^T v_x (:115-117).  NX = 6, NU = 2, 2 x 2: 4 x 4 = 16 items.
   //   pass 2   rows: those of A^T V (1 apart, stride NX) or of B^T V (1 apart, stride NU);  columns: A_j or B_j
   //            -> q_xx, q_ux, q_uu = l + row . column (:117-119).  9 + 3 + 1 = 13 items.
-  // An odd count's last pair overlaps its neighbour (columns of pass 1) or runs one vector past its group (the rest): such a result is
+  // An odd count's last block overlaps its neighbour (columns of pass 1) or runs one vector past its group (the rest): such a result is
   // formed from finite tile contents and written to a pad slot.
-  constexpr int RP1 = (NX + NU + 1) / 2, CN1 = NX + 1, CP1 = (CN1 + 1) / 2, W1 = RP1 * CP1, R1 = (W1 + LPA - 1) / LPA;
-  int p1[R1], q1[R1], b1[R1][2], o1[R1][4];       // results (r0,c0) (r1,c0) (r0,c1) (r1,c1); only column c1 can be v_x, i.e. carry a bias
+  constexpr int BR = (LPA >= 64) ? 1 : 2, BC = (LPA >= 32) ? 1 : 2, BN = BR * BC;
+  constexpr int RP1 = (NX + NU + BR - 1) / BR, CN1 = NX + 1, CP1 = (CN1 + BC - 1) / BC, W1 = RP1 * CP1, R1 = (W1 + LPA - 1) / LPA;
+  int p1[R1], q1[R1], b1[R1][BR], o1[R1][BN];     // result k: row r0 + k % BR, column c0 + k / BR; only the block's LAST column can be v_x, i.e. carry a bias
   MAS_UNROLL for (int r = 0; r < R1; ++r) {
     const int w = lane + r * LPA;
     const bool item = w < W1;
     const int rp = item ? w % RP1 : 0, cp = item ? w / RP1 : 0;
-    const int r0 = 2 * rp, c0 = (2 * cp + 1 < CN1) ? 2 * cp : CN1 - 2;
+    const int r0 = BR * rp, c0 = (BC * cp + BC - 1 < CN1) ? BC * cp : CN1 - BC;
     p1[r] = TL::oD + L::oA + r0 * NX; q1[r] = TL::oV + c0 * NX;
-    MAS_UNROLL for (int k = 0; k < 4; ++k) {
-      const int rr = r0 + (k & 1), cc = c0 + (k >> 1);
-      const bool fresh = item && rr < NX + NU && cc < CN1 && !(cc == c0 && c0 != 2 * cp);    // (the overlapping column was its neighbour's c1)
+    MAS_UNROLL for (int k = 0; k < BN; ++k) {
+      const int rr = r0 + k % BR, cc = c0 + k / BR;
+      const bool fresh = item && rr < NX + NU && cc >= BC * cp;                        // (an overlapping column was its neighbour's)
       const int dst = (cc < NX) ? (rr < NX ? TL::oAtV + cc * NX + rr : TL::oBtV + cc * NU + (rr - NX)) : (rr < NX ? TL::oQx + rr : TL::oQu + (rr - NX));
       o1[r][k] = fresh ? dst : TL::pad_at(w + 4 * k);
-      if (k >> 1) b1[r][k & 1] = (fresh && cc == NX) ? TL::oD + L::oLx + rr : TL::oNegZero;     // (l_u follows l_x in the tile)
+      if (k / BR == BC - 1) b1[r][k % BR] = (fresh && cc == NX) ? TL::oD + L::oLx + rr : TL::oNegZero;     // (l_u follows l_x in the tile)
     }
   }
   static_assert(L::oLu == L::oLx + NX && L::oB == L::oA + NX * NX, "tile layout: B after A, l_u after l_x");
-  constexpr int XP = (NX + 1) / 2, UP = (NU + 1) / 2, W2xx = XP * XP, W2ux = W2xx + UP * XP, W2 = W2ux + UP * UP, R2 = (W2 + LPA - 1) / LPA;
-  int p2[R2], ps2[R2], q2[R2], b2[R2][4], o2[R2][4];   // results (r0,c0) (r1,c0) (r0,c1) (r1,c1), each = T[b] + sum_k T[p + (0|1) + k*ps] * T[q + (0|NX) + k]
+  constexpr int XP = (NX + BR - 1) / BR, UP = (NU + BR - 1) / BR, XC = (NX + BC - 1) / BC, UC = (NU + BC - 1) / BC;
+  constexpr int W2xx = XP * XC, W2ux = W2xx + UP * XC, W2 = W2ux + UP * UC, R2 = (W2 + LPA - 1) / LPA;
+  int p2[R2], ps2[R2], q2[R2], b2[R2][BN], o2[R2][BN];   // result k = T[b] + sum_m T[p + k % BR + m*ps] * T[q + (k / BR) NX + m]
   MAS_UNROLL for (int r = 0; r < R2; ++r) {
     const int w = lane + r * LPA;
     const bool item = w < W2;
     const int kind = !item ? 0 : (w < W2xx) ? 0 : (w < W2ux) ? 1 : 2;                 // q_xx / q_ux / q_uu
     const int e = (kind == 0) ? (item ? w : 0) : (kind == 1) ? w - W2xx : w - W2ux;
     const int rows = (kind == 0) ? NX : NU, cols = (kind == 2) ? NU : NX, rpn = (kind == 0) ? XP : UP;
-    const int r0 = 2 * (e % rpn), c0 = 2 * (e / rpn);
+    const int r0 = BR * (e % rpn), c0 = BC * (e / rpn);
     p2[r] = ((kind == 0) ? TL::oAtV : TL::oBtV) + r0; ps2[r] = rows;
     q2[r] = TL::oD + ((kind == 2) ? L::oB : L::oA) + c0 * NX;
     const int out0 = (kind == 0) ? TL::oQxx : (kind == 1) ? TL::oQux : TL::oQuu, bias0 = TL::oD + ((kind == 0) ? L::oLxx : (kind == 1) ? L::oLux : L::oLuu);
-    MAS_UNROLL for (int k = 0; k < 4; ++k) {
-      const int rr = r0 + (k & 1), cc = c0 + (k >> 1);
+    MAS_UNROLL for (int k = 0; k < BN; ++k) {
+      const int rr = r0 + k % BR, cc = c0 + k / BR;
       const bool fresh = item && rr < rows && cc < cols;
       o2[r][k] = fresh ? out0 + cc * rows + rr : TL::pad_at(w + 4 * k);
       b2[r][k] = fresh ? bias0 + cc * rows + rr : TL::oNegZero;
@@ -155,16 +159,19 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
   // doubles.  No predication: a surplus lane of the short last chunk re-reads the piece's last element and publishes it to
   // its pad slot; fetch and publish are NCH loads and NCH LDS writes with loop-invariant per-lane offsets and one uniform
   // base pointer that steps back by Np*ND doubles per time step.
-  constexpr int NCH = (ND + kTileChunk - 1) / kTileChunk;
-  static_assert(kTileChunk <= LPA, "one lane per chunk element");
+  // With 32 / 64 lanes per agent, 2 / 4 chunks travel per load.
+  constexpr int NCHUNK = (ND + kTileChunk - 1) / kTileChunk, SUB = LPA / kTileChunk, NCH = (NCHUNK + SUB - 1) / SUB;
+  static_assert(LPA % kTileChunk == 0, "whole chunks per load");
   double pre[NCH];
   unsigned fetch_off[NCH]; int publish_at[NCH];
-  MAS_UNROLL for (int c = 0; c < NCH; ++c) {
+  MAS_UNROLL for (int cr = 0; cr < NCH; ++cr) {
+    const int c_raw = cr * SUB + lane / kTileChunk, l16 = lane % kTileChunk;
+    const int c = c_raw < NCHUNK ? c_raw : NCHUNK - 1;                 // (a lane group beyond the last chunk repeats it into pad slots)
     const int cw = (ND - c * kTileChunk < kTileChunk) ? (ND - c * kTileChunk) : kTileChunk;
-    const bool mine = lane < cw;
-    const int e = mine ? lane : cw - 1;
-    fetch_off[c] = static_cast<unsigned>((static_cast<size_t>(a / 64) * 64 * ND + static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
-    publish_at[c] = tile * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + lane : TL::pad_at(TL::oD + c * kTileChunk + lane));
+    const bool mine = c_raw < NCHUNK && l16 < cw;
+    const int e = l16 < cw ? l16 : cw - 1;
+    fetch_off[cr] = static_cast<unsigned>((static_cast<size_t>(a / 64) * 64 * ND + static_cast<size_t>(c) * kTileChunk * 64 + static_cast<size_t>(a % 64) * cw + e) * sizeof(double));
+    publish_at[cr] = tile * TL::STRIDE + (mine ? TL::oD + c * kTileChunk + l16 : TL::pad_at(TL::oD + c * kTileChunk + l16));
   }
   const size_t step_doubles = static_cast<size_t>(d.Np) * ND;
   // (uniform base = the tiles of a time step; the agent's 64-block is part of the lane offset, so that listed agents may come from anywhere)
@@ -236,38 +243,45 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
 
     // ---- pass 1 (ilqr.hpp:115-117: A^T V, B^T V, q_x, q_u)
     {
-      double res[R1][4];
+      double res[R1][BN];
       MAS_UNROLL for (int r = 0; r < R1; ++r) {
-        double pr0[NX], pr1[NX], qc0[NX], qc1[NX];
-        MAS_UNROLL for (int k = 0; k < NX; ++k) { pr0[k] = T[p1[r] + k]; pr1[k] = T[p1[r] + NX + k]; qc0[k] = T[q1[r] + k]; qc1[k] = T[q1[r] + NX + k]; }
-        res[r][0] = sum_terms<NX>([&](int k) { return pr0[k] * qc0[k]; });
-        res[r][1] = sum_terms<NX>([&](int k) { return pr1[k] * qc0[k]; });
-        const double s2 = sum_terms<NX>([&](int k) { return pr0[k] * qc1[k]; }), s3 = sum_terms<NX>([&](int k) { return pr1[k] * qc1[k]; });
-        res[r][2] = T[b1[r][0]] + s2;                                   // l_x / l_u in the v_x column, -0.0 (adds nothing, keeps every bit) elsewhere
-        res[r][3] = T[b1[r][1]] + s3;
+        double pr[BR][NX], qc[BC][NX];
+        MAS_UNROLL for (int k = 0; k < NX; ++k) {
+          MAS_UNROLL for (int br = 0; br < BR; ++br) pr[br][k] = T[p1[r] + br * NX + k];
+          MAS_UNROLL for (int bc = 0; bc < BC; ++bc) qc[bc][k] = T[q1[r] + bc * NX + k];
+        }
+        MAS_UNROLL for (int k = 0; k < BN; ++k) {
+          const double s = sum_terms<NX>([&](int m) { return pr[k % BR][m] * qc[k / BR][m]; });
+          res[r][k] = (k / BR == BC - 1) ? T[b1[r][k % BR]] + s : s;    // l_x / l_u in the v_x column, -0.0 (adds nothing, keeps every bit) elsewhere
+        }
       }
-      MAS_UNROLL for (int r = 0; r < R1; ++r) { MAS_UNROLL for (int k = 0; k < 4; ++k) T[o1[r][k]] = res[r][k]; }      // idle results: own pad slots
+      MAS_UNROLL for (int r = 0; r < R1; ++r) { MAS_UNROLL for (int k = 0; k < BN; ++k) T[o1[r][k]] = res[r][k]; }      // idle results: own pad slots
     }
     wave_sync();
     double quu[NU * NU], Lfac[NU * NU], ninv[NU * NU];
+    constexpr bool kLaneExchange = NU <= 2;     // q_uu and the winning factor travel lane to lane (DPP / ds_bpermute), not through the tile
     // ---- pass 2 (ilqr.hpp:117-119: q_xx, q_ux, q_uu)
     {
-      double res[R2][4];
+      double res[R2][BN];
       MAS_UNROLL for (int r = 0; r < R2; ++r) {
-        double pr0[NX], pr1[NX], qc0[NX], qc1[NX];
-        MAS_UNROLL for (int k = 0; k < NX; ++k) { pr0[k] = T[p2[r] + k * ps2[r]]; pr1[k] = T[p2[r] + k * ps2[r] + 1]; qc0[k] = T[q2[r] + k]; qc1[k] = T[q2[r] + NX + k]; }
-        const double s0 = sum_terms<NX>([&](int k) { return pr0[k] * qc0[k]; }), s1 = sum_terms<NX>([&](int k) { return pr1[k] * qc0[k]; });
-        const double s2 = sum_terms<NX>([&](int k) { return pr0[k] * qc1[k]; }), s3 = sum_terms<NX>([&](int k) { return pr1[k] * qc1[k]; });
-        res[r][0] = T[b2[r][0]] + s0; res[r][1] = T[b2[r][1]] + s1; res[r][2] = T[b2[r][2]] + s2; res[r][3] = T[b2[r][3]] + s3;
+        double pr[BR][NX], qc[BC][NX];
+        MAS_UNROLL for (int k = 0; k < NX; ++k) {
+          MAS_UNROLL for (int br = 0; br < BR; ++br) pr[br][k] = T[p2[r] + k * ps2[r] + br];
+          MAS_UNROLL for (int bc = 0; bc < BC; ++bc) qc[bc][k] = T[q2[r] + bc * NX + k];
+        }
+        MAS_UNROLL for (int k = 0; k < BN; ++k) {
+          const double s = sum_terms<NX>([&](int m) { return pr[k % BR][m] * qc[k / BR][m]; });
+          res[r][k] = T[b2[r][k]] + s;
+        }
       }
-      MAS_UNROLL for (int r = 0; r < R2; ++r) { MAS_UNROLL for (int k = 0; k < 4; ++k) T[o2[r][k]] = res[r][k]; }
-      if constexpr (LPA == 16) {
-        // q_uu straight from the lanes that formed it (an agent's 16 lanes are one DPP row): the LLT / ladder chain starts without
-        // waiting for the LDS round trip of the other pass-2 results
-        tile_gather_quu<NU, W2ux, UP>(res, quu, std::make_integer_sequence<int, NU * NU>{});
+      MAS_UNROLL for (int r = 0; r < R2; ++r) { MAS_UNROLL for (int k = 0; k < BN; ++k) T[o2[r][k]] = res[r][k]; }
+      if constexpr (LPA == 16 || kLaneExchange) {
+        // q_uu straight from the lanes that formed it: the LLT / ladder chain starts without waiting for the LDS round trip of the
+        // other pass-2 results
+        tile_gather_quu<NU, W2ux, UP, BR, BC, LPA>(res, quu, tid & ~(LPA - 1), std::make_integer_sequence<int, NU * NU>{});
       }
     }
-    if constexpr (LPA != 16) {
+    if constexpr (!(LPA == 16 || kLaneExchange)) {
       wave_sync();
       MAS_UNROLL for (int i = 0; i < NU * NU; ++i) quu[i] = T[TL::oQuu + i];
     }
@@ -364,7 +378,7 @@ __global__ void __launch_bounds__(64 * WPB) mas_backward_tile_kernel(Dims d, Mod
         }
         }
         if (lane == 0 && (!SharedLadder || a == 0)) regs += win;         // the stacked solve counts its rungs once (agent 0)
-        if constexpr (NU <= 2 && LPA == 16) {
+        if constexpr (kLaneExchange) {
           // the factor of the winning rung straight from its lane (ds_bpermute), see mas_backward_row_kernel
           const int src = ((tid & ~(LPA - 1)) + (win & (LL - 1))) * 4;
           MAS_UNROLL for (int e = 0; e < NU * NU; ++e) {

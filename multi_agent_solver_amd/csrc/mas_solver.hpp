@@ -96,6 +96,8 @@ class SolverBase {
     long long forward_quad_max = 1600;      // four-lanes-per-rollout line search up to this many live agents (0: never)
     bool backward_tile = false;             // the LDS-tile backward kernel also for NX == 4
     bool backward_list = true;              // the LDS-tile kernel walks the round's list of live agents
+    long long backward_wide_max = 4096;     // LDS-tile kernel with 32 lanes per agent up to this many live agents (0: never), NX > 4
+    long long backward_wave_max = 1024;     // ... with a whole wavefront per agent up to this many
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
@@ -105,6 +107,8 @@ class SolverBase {
       else if (key == "forward_quad_max") forward_quad_max = v;
       else if (key == "backward_tile") backward_tile = v != 0;
       else if (key == "backward_list") backward_list = v != 0;
+      else if (key == "backward_wide_max") backward_wide_max = v;
+      else if (key == "backward_wave_max") backward_wave_max = v;
       else if (key == "central_pipeline") central_pipeline = v != 0;
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
@@ -115,7 +119,7 @@ class SolverBase {
     }
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
-      static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "central_pipeline", "central_one_xcd",
+      static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "central_pipeline", "central_one_xcd",
                                    "force_single_workgroup_central", "central_combine", "central_wpb"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
@@ -769,11 +773,27 @@ class SolverImpl final : public SolverBase {
       }
     }
     LadderSync extras{};
-    dim3 tile_grid = grid;
-    if (live_list != nullptr && backward_list_enabled()) {
-      extras.live_list = live_list; extras.live_count = live_count;
-      tile_grid = dim3(static_cast<unsigned>((slots + wpb * apw - 1) / (wpb * apw)));
+    const bool listed = live_list != nullptr && backward_list_enabled();
+    if (listed) { extras.live_list = live_list; extras.live_count = live_count; }
+    const long long agents = listed ? slots : hi - lo;
+    // Tail rounds of a solve (few live agents: the launch is as long as ONE wavefront's chain of instructions): 32 lanes per agent,
+    // half the dot products per lane.  While the agents fill the chip the 16-lane form does the same work with half the wavefronts.
+    if constexpr (NX > 4 && kLanes == 16) {
+      if (agents <= switches.backward_wave_max) {
+        be.launch_kernel(mas_backward_tile_kernel<M, 64, false, wpb>, dim3(static_cast<unsigned>((agents + wpb - 1) / wpb)), dim3(64 * wpb),
+                         d, P, X, D, kff, Kfb, reg_events, active, lo, hi, extras);
+        be.end();
+        return;
+      }
+      if (agents <= switches.backward_wide_max) {
+        constexpr int apw_wide = 2;
+        be.launch_kernel(mas_backward_tile_kernel<M, 32, false, wpb>, dim3(static_cast<unsigned>((agents + wpb * apw_wide - 1) / (wpb * apw_wide))), dim3(64 * wpb),
+                         d, P, X, D, kff, Kfb, reg_events, active, lo, hi, extras);
+        be.end();
+        return;
+      }
     }
+    const dim3 tile_grid(static_cast<unsigned>((agents + wpb * apw - 1) / (wpb * apw)));
     be.launch_kernel(mas_backward_tile_kernel<M, kLanes, false, wpb>, tile_grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
                      reg_events, active, lo, hi, extras);
     be.end();

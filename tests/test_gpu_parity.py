@@ -437,17 +437,22 @@ def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
     LDS-tile form.  Which form runs depends on the number of live agents and the model; here the same perturbed problem is
     solved with the new forms (default: 330 agents are below the four-lane bound from round 0 on) and with the round-1 forms
     forced through mas_hip_set_option -- equal results (and both equal to the oracle).  Round 3: the default is also the two-kernel
-    fused round (mas_fused_hip.hpp) for the four-state models; "fused": 0 gives the five-kernel round with the new forms."""
+    fused round (mas_fused_hip.hpp) for the four-state models; "fused": 0 gives the five-kernel round with the new forms.  For
+    the six-state model the default at 330 agents is the LDS-tile kernel with 64 lanes per agent ("backward_wave_max": 0: 32 lanes, and
+    "backward_wide_max": 0: 16 lanes)."""
     mid = getattr(oracle, model)
     N = 330
     rng = np.random.default_rng(7)
     base = {"MODEL_LQR_IDENTITY": lambda: oracle.lqr_x0(N), "MODEL_BICYCLE6": lambda: oracle.bicycle6_x0(N)}.get(model, lambda: oracle.single_track_x0(N))()
     x0 = base + 0.05 * rng.standard_normal(base.shape)
     new = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer)
-    old = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"fused": 0, "forward_quad_max": 0, "backward_tile": 1})
+    old = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"fused": 0, "forward_quad_max": 0, "backward_tile": 1, "backward_wide_max": 0, "backward_wave_max": 0})
     unfused = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"fused": 0})
     fused_one_lane = run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"forward_quad_max": 0})
-    for other in (old, unfused, fused_one_lane):
+    others = [old, unfused, fused_one_lane]
+    if model == "MODEL_BICYCLE6":     # default here: a whole wavefront per agent in the backward pass; 32 lanes per agent; (old: 16)
+        others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"backward_wave_max": 0}))
+    for other in others:
         for key in ("cost", "X", "U", "iters", "status"):
             assert np.array_equal(new[key], other[key]), key
         assert new["stats"]["reg_events"] == other["stats"]["reg_events"]

@@ -51,8 +51,9 @@ for c in range(cases):
         x0 = rng.standard_normal((N, nx))
     U0 = None if rng.random() < 0.4 or strategy.startswith("centralized") else 0.1 * rng.standard_normal((N, T, nu))
     # kernel forms (bit-identical alternatives, mas_hip_set_option): two-kernel fused rounds or the five-kernel round, the four-lane line
-    # search never / up to 1600 live agents / always
-    forms = {"fused": int(rng.choice([0, 1, 1, 1])), "forward_quad_max": int(rng.choice([0, 1600, 1600, 1000000]))}
+    # search never / up to 1600 live agents / always, the LDS-tile backward kernel with 16 lanes per agent only / 32 / 64 lanes for few live agents
+    forms = {"fused": int(rng.choice([0, 1, 1, 1])), "forward_quad_max": int(rng.choice([0, 1600, 1600, 1000000])),
+             "backward_wide_max": int(rng.choice([0, 4096, 4096])), "backward_wave_max": int(rng.choice([0, 1024, 1024]))}
     with BatchSolver(model, N, T, DT[model]) as s:
         for key, value in forms.items():
             s.set_option(key, value)
