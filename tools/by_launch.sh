@@ -1,10 +1,10 @@
 #!/bin/bash
 # duration of every launch of one strategy run, in launch order, and the gaps between consecutive launches (rocprofv3 kernel trace)
-#   tools/by_launch.sh [c3|c2|c4|c5] [agents]
-W=${1:-c3}; N=${2:-}
+#   tools/by_launch.sh [c3|c2|c4|c5] [agents] [--option key=value ...]
+W=${1:-c3}; N=${2:-}; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/bylaunch_$W
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/bylaunch_$W -o t -- python3 tools/one_run.py $W $N > gpurun_out/bylaunch_$W.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/bylaunch_$W -o t -- python3 tools/one_run.py $W $N "$@" > gpurun_out/bylaunch_$W.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 rows = []
