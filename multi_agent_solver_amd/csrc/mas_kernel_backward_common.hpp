@@ -69,14 +69,13 @@ __device__ __forceinline__ double sum_terms(F term) {
 }
 
 
-// Per time step the wavefront makes three passes over its four LDS tiles, every lane running the
-// same instruction stream on its own operand addresses (no divergence inside a pass):
-//   pass 1   A^T V, B^T V, q_x, q_u                       (length-NX dot products)
-//   pass 2   q_xx, q_ux, q_uu                             (length-NX dot products)
-//   pass 3   LLT + regularisation ladder, Quu^-1, gains, value update, symmetrisation -- all in
-//            registers: each lane rebuilds the two gain columns and the two rows of K^T q_uu it needs,
-//            evaluates its own and its mirror entry of v_xx and applies the reference's aliased
-//            in-place symmetrisation rule, so no further exchange is needed.
+// Per time step the wavefront makes three passes over its LDS tiles (four agents x 16 lanes, two x 32 or one x 64), every lane
+// running the same instruction stream on its own operand addresses (no divergence inside a pass):
+//   pass 1   A^T V, B^T V, q_x, q_u                       (length-NX dot products, a block of them per lane)
+//   pass 2   q_xx, q_ux, q_uu                             (length-NX dot products, a block of them per lane)
+//   pass 3   LLT + regularisation ladder and Quu^-1 in registers (every lane: 16 rungs at once); stage A: lane c forms column c
+//            of [K | k] and of its product with q_uu, once; stage B: one lane per PAIR of mirrored v_xx entries (and per v_x
+//            entry) applies the value update and the reference's aliased in-place symmetrisation rule.
 // Rung agreement of the centralised strategy (SharedLadder): the stacked q_uu is block-diagonal, its LLT fails if
 // ANY block fails and reg*I is then added to EVERY block (ilqr.hpp:172-182), so all agents use the first rung at
 // which all of them succeed.  Per (time step, chunk of 16 rungs) there is ONE 64-bit word: every wavefront ORs the rungs

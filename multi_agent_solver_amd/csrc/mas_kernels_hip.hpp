@@ -12,8 +12,9 @@
 //                                round trip per step.
 //  * mas_backward_row_pipelined_kernel  the same with the shared ladder of the centralised strategy, the cross-workgroup rung
 //                                agreement hidden behind a speculative step.
-//  * mas_backward_tile_kernel    backward recursion for any NX with SIXTEEN lanes per agent over an LDS tile per agent: the small
-//                                dense products of ilqr.hpp:115-119,183-192 are spread element-wise over the 16 lanes.
+//  * mas_backward_tile_kernel    backward recursion for any NX over an LDS tile per agent, 16 lanes per agent (32 / 64 when few agents
+//                                are live): the small dense products of ilqr.hpp:115-119,183-192 are dealt to the lanes as blocks of
+//                                dot products, the gains are formed once per step, v_xx by pairs of mirrored entries.
 // All backward kernels compute, element for element, the arithmetic of BackwardBody (the one-lane form the host emulation
 // replays): every output element is the same sequence of multiplies and adds, sums in k order (sum_terms: from the first term).
 // Their time-step loops are written against the gfx950 ISA they compile to: a lone wavefront per SIMD pays 5.5-7 clock ticks per
