@@ -31,3 +31,21 @@ def test_block_diagonal_reading_lies_inside_the_literal_solves_own_band(curve):
     for c in curve:
         assert c["block_diagonal_vs_literal_total_rel"] <= min(ABSOLUTE_BOUND, BAND_FACTOR * band), c
         assert np.isfinite(c["block_diagonal_vs_literal_per_agent_max_rel"])
+
+
+def test_committed_curve_to_64_agents(curve):
+    """profiles/r3_c2_readings_curve.json (tools/c2_readings_curve.py, minutes of CPU at 64 agents) extends the curve to the sizes VERDICT r2
+    item 6 named (32-64 agents).  Its rows up to 16 agents must be what the oracle computes here (so the file is the oracle's, not an
+    edited, curve); the statement about the band is asserted on all of its rows."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3_c2_readings_curve.json")
+    rows = {r["agents"]: r for r in json.load(open(path))["curve"]}
+    assert {2, 4, 8, 16, 32, 64} <= set(rows)
+    for c in curve:
+        if c["agents"] in rows:
+            for key in ("block_diagonal_vs_literal_total_rel", "iterations_literal", "iterations_block_diagonal", "literal_under_one_ulp_inputs_total_rel"):
+                assert rows[c["agents"]][key] == c[key], (c["agents"], key)
+    band = max(max(r["literal_under_one_ulp_inputs_total_rel"]) for r in rows.values())
+    for r in rows.values():
+        assert r["block_diagonal_vs_literal_total_rel"] <= min(ABSOLUTE_BOUND, BAND_FACTOR * band), r

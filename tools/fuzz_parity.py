@@ -15,6 +15,7 @@ from multi_agent_solver_amd.batch import BatchSolver  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 BIG = int(os.environ.get("FUZZ_BIG", "1"))      # agent-count multiplier (FUZZ_BIG=8: batches of thousands, slower oracle)
+ONLY = int(os.environ.get("FUZZ_MODEL", "0"))   # 1..6: that model only, with the large agent counts (e.g. 5: bicycle6 across the 16 / 32 / 64-lane backward forms)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
@@ -23,10 +24,10 @@ DT = {1: 0.5, 2: 0.1, 3: 0.05, 4: 0.1, 5: 0.25, 6: 0.5}
 bad = 0
 t0 = time.time()
 for c in range(cases):
-    model = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 6]))
+    model = ONLY if ONLY else int(rng.choice([1, 1, 1, 2, 3, 4, 5, 6]))
     nx, nu, _ = O.model_dims(model)
     strategy = str(rng.choice(["single", "sequential", "trustregion", "linesearch", "centralized", "centralized_dense"]))
-    N = int(rng.integers(1, 700 * BIG)) if model in (1, 2, 6) else int(rng.integers(1, 80 * BIG))
+    N = int(rng.integers(1, 700 * BIG)) if (model in (1, 2, 6) or ONLY) else int(rng.integers(1, 80 * BIG))
     T = int(rng.integers(1, 60))
     if model == 3:
         N, T = int(rng.integers(1, 4)), int(rng.integers(5, 40))
