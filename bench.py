@@ -233,7 +233,7 @@ def parity_block(w, sol, n_total, max_agents=4096):
             "agents": int(idx.size), "bounds": bounds, "worst_over_variants": worst, "per_variant": per,
             "met": bool(all(worst[k] <= bounds[k] for k in bounds))}
     if w["strategy"] == "centralized":
-        # the reference's literal centralised algorithm (finite differences of the SUMMED cost) is computable up to 16 agents: its deviation
+        # the reference's literal centralised algorithm (finite differences of the SUMMED cost) is computable up to 64 agents on the device (seconds beyond 16) and at any size by the oracle: its deviation
         # from the block-diagonal reading AT THIS HORIZON, next to its own deviation under one-ulp inputs (tests/test_centralized_readings.py)
         from oracle import oracle as O
         from oracle.population import centralized_reading_deviation
@@ -245,7 +245,7 @@ def parity_block(w, sol, n_total, max_agents=4096):
         out["vs_reference_stacked_solve"] = {
             "statement": "NOT the same number: the reference finite-differences the summed cost of the stacked problem (centralized.hpp:18-38, multi_agent_problem.hpp:94-122), "
                          "whose Hessians carry FD noise in the cross-agent blocks; this path solves the block-diagonal reading (the literal solve is 4*(4N)^2 evaluations of "
-                         "the N-agent cost per time step: on the device up to 16 agents, mas_hip_run_centralized_dense, bit-equal to the oracle's).  At this horizon the two "
+                         "the N-agent cost per time step: on the device up to 64 agents, mas_hip_run_centralized_dense, bit-equal to the oracle's; profiles/r3_c2_readings_curve.json holds this curve to 64 agents).  At this horizon the two "
                          "differ by tens of per cent of the total cost -- and so does the literal solve from ITSELF when one input coordinate moves by one ulp: both stall on "
                          "the same finite-difference noise after a few iterations.  At T = 10 they agree to 5e-3 (tests/test_gpu_parity.py).",
             "curve_at_this_horizon": curve,

@@ -518,10 +518,10 @@ inline void initialize_agents(MultiAgentProblem& problem) {
 
 // ----------------------------------------------------------------------- strategies ------
 // strategies/centralized.hpp:10-39.  The reference stacks all agents into one OCP and finite-differences the SUMMED cost
-// (dense cross-agent Hessians): `Literal` is that solve on the device (mas_hip_run_centralized_dense, <= 16 agents -- it is
-// 4 (N nx)^2 evaluations of the N-agent cost per time step); `Blocked` is the block-diagonal reading that scales
+// (dense cross-agent Hessians): `Literal` is that solve on the device (mas_hip_run_centralized_dense, <= 64 agents -- it is
+// 4 (N nx)^2 evaluations of the N-agent cost per time step: seconds beyond 16 agents); `Blocked` is the block-diagonal reading that scales
 // (mas_hip_run_centralized, <= 1024 agents; a different number).  `Auto` takes the literal solve
-// where it exists, so that small problems -- the reference's own example defaults to 10 agents -- get the reference's number.
+// up to 16 agents, so that small problems -- the reference's own example defaults to 10 agents -- get the reference's number.
 struct CentralizedStrategy {
   enum class Reading { Auto, Literal, Blocked };
   static constexpr int kLiteralMaxAgents = 16;

@@ -59,4 +59,5 @@ def centralized_reading_deviation(O, n_agents, T=100, dt=0.5):
                 block_diagonal_vs_literal_total_rel=float(abs(blk["total_cost"] - lit["total_cost"]) / abs(lit["total_cost"])),
                 block_diagonal_vs_literal_per_agent_max_rel=float(np.max(np.abs(blk["cost"] - lit["cost"]) / np.abs(lit["cost"]))),
                 iterations_literal=int(lit["iters"][0]), iterations_block_diagonal=int(blk["iters"][0]),
+                literal_total_cost=float(lit["total_cost"]), block_diagonal_total_cost=float(blk["total_cost"]),
                 literal_under_one_ulp_inputs_total_rel=[float(v) for v in self_dev], literal_under_one_ulp_inputs_iterations=self_iters)

@@ -236,5 +236,5 @@ def test_centralized_dense_other_models_and_limits(hostcheck_lib, oracle):
     o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0, None, 12, 0.1, strategy="centralized_dense")
     _same(e, o)
     from multi_agent_solver_amd._capi import MasHipError
-    with pytest.raises(MasHipError):                                      # 17 agents: beyond the literal solve's limit, loudly
-        run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(17), None, 5, 0.5, "centralized_dense")
+    with pytest.raises(MasHipError):                                      # 65 agents: beyond the literal solve's limit, loudly
+        run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(65), None, 5, 0.5, "centralized_dense")
