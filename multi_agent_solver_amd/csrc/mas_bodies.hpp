@@ -318,6 +318,9 @@ struct SelectBody {
   int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // "debug" trace: iteration number (0 = idle) and d_merit per agent
   int* ended = nullptr;                // non-null: 1 for every agent whose solve ended in this iteration, else 0 (chained trust-region epilogue)
   int* slot_out = nullptr;             // non-null (with next_list): slot_out[a] = the agent's position in next_list (fused rounds: where its trial column lies)
+  // non-null: the agents whose solve ended in this iteration, compacted (any order) -- one workgroup each in mas_trust_epilogue_kernel.
+  // Two counters alternate by round: this one is counted up, ended_clear (the other one, read by the epilogue of the round before) reset.
+  int* ended_list = nullptr; int* ended_count = nullptr; int* ended_clear = nullptr;
   MAS_HD bool out_of_time(int a) const {
     if (!solve_start) return false;
     const double elapsed_ms = static_cast<double>(static_cast<long long>(static_cast<double>(MAS_NOW_TICKS() - solve_start[a]) / kTicksPerMs));
@@ -342,6 +345,7 @@ struct SelectBody {
   }
   MAS_HD int decide_(int a) const {
     if (a == 0 && clear) { clear[0] = 0; clear[1] = 0; }
+    if (a == 0 && ended_clear) *ended_clear = 0;
     if (!active[a]) { alpha_sel[a] = -1; if (dbg_iter) dbg_iter[a] = 0; return kIdle; }
     const double cur = merit[a];
     int sel = -1; double best = cur;
@@ -396,9 +400,20 @@ struct SelectBody {
         if (slot_out) slot_out[a] = pos;
       }
     }
+    if (ended_list) {
+      const unsigned long long done = __ballot(r == kConverged || r == kRetired || (r & kChained) != 0);
+      if (done != 0ull) {
+        const int leader = __builtin_ctzll(done);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(ended_count, __popcll(done));
+        base = __shfl(base, leader);
+        if ((done >> lane) & 1ull) ended_list[base + __popcll(done & ((1ull << lane) - 1ull))] = a;
+      }
+    }
 #else
     if ((r & ~kChained) == kConverged) MAS_ATOMIC_ADD_I64(n_converged, 1LL);
     if (r == kStillActive || (r & kChained) != 0) { if (next_list) { next_list[*n_active] = a; if (slot_out) slot_out[a] = *n_active; } MAS_ATOMIC_ADD_INT(n_active, 1); }
+    if (ended_list && (r == kConverged || r == kRetired || (r & kChained) != 0)) ended_list[(*ended_count)++] = a;
 #endif
   }
 };
@@ -494,6 +509,7 @@ struct BeginSolveBody {
   int* solves_left = nullptr; int chained = 0;                 // further solves every agent runs back to back after this one
   unsigned long long* solve_start = nullptr;                   // non-null: finite max_ms, stamp the start of the solve (ilqr.hpp:61)
   int* slot_of = nullptr;                                      // non-null: position of every agent in the identity list (fused rounds)
+  int* ended_counts = nullptr;                                 // non-null: the two alternating counters of SelectBody::ended_list, zeroed by agent 0
   MAS_HD void operator()(int a) const {
     active[a] = 1; iters_solve[a] = 0; exit_code[a] = kExitMaxIter; alpha_sel[a] = -1;
     if (slot_of) slot_of[a] = a;
@@ -501,7 +517,7 @@ struct BeginSolveBody {
     if (solves_left) solves_left[a] = chained;
     if (merit) merit[a] = cost[a];
     if (live_list) live_list[a] = a;
-    if (a == 0) { for (int i = 0; i < n_counters; ++i) counters[i] = 0; if (live_count) *live_count = n_agents; }
+    if (a == 0) { for (int i = 0; i < n_counters; ++i) counters[i] = 0; if (live_count) *live_count = n_agents; if (ended_counts) { ended_counts[0] = 0; ended_counts[1] = 0; } }
   }
 };
 

@@ -31,6 +31,7 @@
 //   mas_kernel_backward_common.hpp   row_bcast, llt_solve_identity_by_columns, sum_terms, LadderSync (the rung agreement)
 //   mas_kernel_backward_tile.hpp     BackwardTileLayout, mas_backward_tile_kernel
 //   mas_kernel_backward_row.hpp      mas_backward_row_kernel, mas_backward_row_pipelined_kernel
+//   mas_kernel_levels.hpp            open-loop rollouts by dependency levels (all time steps of a level side by side), mas_trust_epilogue_kernel
 //   mas_fused_hip.hpp                mas_linearise_riccati_kernel (the two-kernel round of the four-state models; includes this file)
 #pragma once
 
@@ -42,3 +43,4 @@
 #include "mas_kernel_backward_common.hpp"
 #include "mas_kernel_backward_tile.hpp"
 #include "mas_kernel_backward_row.hpp"
+#include "mas_kernel_levels.hpp"

@@ -27,9 +27,12 @@ MAS_HD void perturb2(const double* v, int i, double si, int j, double sj, double
 }
 MAS_HD double safe_value(double v) { return std::isfinite(v) ? v : 0.0; }   // finite_differences.hpp:95-107
 
-// integrate_rk4, integrator.hpp:19-28
+// integrate_rk4, integrator.hpp:19-28, in two statements: the increment (dt/6)(k1 + 2 k2 + 2 k3 + k4) and its addition to x.  (Nothing
+// is contracted, so `x + inc` is the reference's `x + (dt/6) * (...)` bit for bit.)  The increment alone is what the rollout by
+// dependency levels needs (mas_kernel_levels.hpp): for the vehicle models the increment of a state component depends only on
+// components of lower levels, never on the component itself.
 template <class M>
-MAS_HD void rk4_step(const double* x, const double* u, double dt, double* out, const ModelParams& P) {
+MAS_HD void rk4_increment(const double* x, const double* u, double dt, double* inc, const ModelParams& P) {
   constexpr int NX = M::NX;
   double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
   const typename M::Ctl c = M::prepare(u, P);      // u is held over the step: its own terms once
@@ -40,7 +43,14 @@ MAS_HD void rk4_step(const double* x, const double* u, double dt, double* out, c
   M::dynamics_c(xs, u, c, k3, P);
   MAS_UNROLL for (int i = 0; i < NX; ++i) xs[i] = x[i] + dt * k3[i];
   M::dynamics_c(xs, u, c, k4, P);
-  MAS_UNROLL for (int i = 0; i < NX; ++i) out[i] = x[i] + (dt / 6.0) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) inc[i] = (dt / 6.0) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+}
+template <class M>
+MAS_HD void rk4_step(const double* x, const double* u, double dt, double* out, const ModelParams& P) {
+  constexpr int NX = M::NX;
+  double inc[NX];
+  rk4_increment<M>(x, u, dt, inc, P);
+  MAS_UNROLL for (int i = 0; i < NX; ++i) out[i] = x[i] + inc[i];
 }
 
 // clamp_controls on one column, constraint_helpers.hpp:107-114: cwiseMin(upper).cwiseMax(lower)

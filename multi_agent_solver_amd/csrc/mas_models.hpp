@@ -31,6 +31,11 @@ struct NoConstraints {
   static constexpr int NEQ = 0, NIN = 0;
   // true: the dynamics have a four-lanes-per-rollout RK4 (QuadRk4, mas_kernels_hip.hpp) for launches that do not fill the chip
   static constexpr bool kQuadRk4 = false;
+  // > 0: the state components fall into that many DEPENDENCY LEVELS -- the RK4 increment of a component (rk4_increment, mas_lane.hpp)
+  // depends only on the control and on components of LOWER levels (state_level(i)), never on the component itself or its peers --
+  // so an open-loop rollout can be evaluated level by level, all time steps of a level side by side (mas_kernel_levels.hpp)
+  static constexpr int kRolloutLevels = 0;
+  MAS_HD static constexpr int state_level(int) { return 0; }
   MAS_HD static void equality(const double*, const double*, double*, const ModelParams&) {}
   MAS_HD static void inequality(const double*, const double*, double*, const ModelParams&) {}
 };
@@ -48,6 +53,8 @@ struct SingleTrack : NoConstraints {
   static constexpr bool kZeroTerminal = true;   // terminal_cost == 0 (:65): FD of it is exactly 0
   static constexpr bool kDefaultBounds = true;
   static constexpr bool kQuadRk4 = true;        // psi and v advance without sin/cos: the four RK4 stages' sin/cos can run side by side
+  static constexpr int kRolloutLevels = 3;      // v <- a;  psi <- v, delta;  X, Y <- v, psi
+  MAS_HD static constexpr int state_level(int i) { return i == 3 ? 0 : i == 2 ? 1 : 2; }
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
 
   // the part of f(x,u) that depends on u alone: RK4 evaluates f four times with the same zero-order-
@@ -184,6 +191,8 @@ struct SingleTrackLane : NoConstraints {
   static constexpr bool kZeroTerminal = true;
   static constexpr bool kDefaultBounds = true;
   static constexpr bool kQuadRk4 = true;        // SingleTrack's dynamics
+  static constexpr int kRolloutLevels = SingleTrack::kRolloutLevels;
+  MAS_HD static constexpr int state_level(int i) { return SingleTrack::state_level(i); }
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -0.7; lb[1] = -1.0; ub[0] = 0.7; ub[1] = 1.0; }
 
   using Ctl = SingleTrack::Ctl;
@@ -234,6 +243,8 @@ struct Bicycle6 : NoConstraints {
   static constexpr bool kZeroTerminal = true;
   static constexpr bool kDefaultBounds = true;
   static constexpr bool kQuadRk4 = true;        // a, delta, v, psi of every RK4 stage follow from x and u without sin/cos
+  static constexpr int kRolloutLevels = 4;      // delta, a <- u;  v <- a;  psi <- v, delta;  X, Y <- v, psi
+  MAS_HD static constexpr int state_level(int i) { return i >= 4 ? 0 : i == 3 ? 1 : i == 2 ? 2 : 3; }
   MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
 
   MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {

@@ -98,6 +98,8 @@ class SolverBase {
     bool backward_list = true;              // the LDS-tile kernel walks the round's list of live agents
     long long backward_wide_max = 4096;     // LDS-tile kernel with 32 lanes per agent up to this many live agents (0: never), NX > 4
     long long backward_wave_max = 1024;     // ... with a whole wavefront per agent up to this many
+    bool trust_reroll_levels = true;        // the re-roll of the three-kernel epilogue by dependency levels (a workgroup per queued agent) instead of four lanes per rollout
+    long long trust_fused_max = 4096;       // chained trust-region epilogue as ONE kernel (re-roll by dependency levels, mas_kernel_levels.hpp) up to this many live agents (0: never)
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
@@ -109,6 +111,8 @@ class SolverBase {
       else if (key == "backward_list") backward_list = v != 0;
       else if (key == "backward_wide_max") backward_wide_max = v;
       else if (key == "backward_wave_max") backward_wave_max = v;
+      else if (key == "trust_fused_max") trust_fused_max = v;
+      else if (key == "trust_reroll_levels") trust_reroll_levels = v != 0;
       else if (key == "central_pipeline") central_pipeline = v != 0;
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
@@ -119,7 +123,7 @@ class SolverBase {
     }
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
-      static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "central_pipeline", "central_one_xcd",
+      static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
                                    "force_single_workgroup_central", "central_combine", "central_wpb"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
@@ -249,6 +253,15 @@ class SolverImpl final : public SolverBase {
   }
   void launch_trust_reroll(const TrustRerollBody<M>& body) {
 #if !defined(MAS_HOST_EMULATION)
+    if constexpr (M::kRolloutLevels > 0 && !kConstrained) {      // by dependency levels, a workgroup per queued agent (mas_kernel_levels.hpp); the grid is bounded by the live count
+      using LV = LevelsLayout<M>;
+      if (switches.trust_reroll_levels && LV::bytes(d.T) <= 150 * 1024) {
+        be.begin("trust_reroll", 0.0);
+        be.launch_kernel_lds(mas_trust_reroll_levels_kernel<M>, dim3(static_cast<unsigned>(std::min<long long>(std::max<long long>(live_upper, 1), d.N))), dim3(LV::kThreads), LV::bytes(d.T), body);
+        be.end();
+        return;
+      }
+    }
     if constexpr (M::kQuadRk4 && !kConstrained) {
       if (quad_forward_max_slots() > 0) {
         be.begin("trust_reroll", 0.0);
@@ -711,6 +724,25 @@ class SolverImpl final : public SolverBase {
   long long quad_forward_max_slots() const {
     return switches.forward_quad_max;
   }
+  // chained trust-region epilogue as one kernel (mas_trust_epilogue_kernel): vehicle models, rounds with at most trust_fused_max live
+  // agents (the grid is bounded by the live count: at most that many solves can have ended).  false: the three-kernel form runs.
+  bool launch_trust_epilogue(const int* ended_count) {
+#if !defined(MAS_HOST_EMULATION)
+    if constexpr (M::kRolloutLevels > 0 && !kConstrained) {
+      using LV = LevelsLayout<M>;
+      if (live_upper <= switches.trust_fused_max && LV::bytes(d.T) <= 150 * 1024) {
+        const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
+        be.begin("trust_epilogue", 0.0);
+        be.launch_kernel_lds(mas_trust_epilogue_kernel<M>, dim3(static_cast<unsigned>(std::min<long long>(live_upper, d.N))), dim3(LV::kThreads), LV::bytes(d.T),
+                             d, dt, P, static_cast<const double*>(x0), X, U, X_old, U_old, ts, static_cast<const int*>(trust_ended_list), ended_count);
+        be.end();
+        return true;
+      }
+    }
+#endif
+    (void)ended_count;
+    return false;
+  }
   // backward pass of the stacked problem: the 16-lane tile kernel with the rung agreement across all wavefronts
   // (LadderSync); constrained models and the host emulation keep the one-workgroup body
   void launch_central_backward(double bytes) {
@@ -893,6 +925,7 @@ class SolverImpl final : public SolverBase {
     controls_zero = false;
     if (trust_epilogue && !trust_verdict) {
       trust_verdict = ialloc(d.Np); trust_ended = ialloc(d.Np); trust_roll_list = ialloc(d.Np); trust_roll_count = ialloc(16); trust_scale = dalloc(d.Np);
+      trust_ended_list = ialloc(d.Np); trust_ended_counts = ialloc(16);
     }
     // x = integrate_horizon(x0, best_controls); cost = objective; merit (ilqr.hpp:75-78).  After
     // initialize_problem / a previous solve / a strategy epilogue the device already holds exactly that
@@ -907,7 +940,8 @@ class SolverImpl final : public SolverBase {
     if (debug && !dbg_iter) { dbg_iter = ialloc(d.Np); dbg_improvement = dalloc(d.Np); }
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel, cost, rollout_consistent ? merit : nullptr,
                                                            counters, 2 * kCounterRing, live_lists[0], live_count0, d.N,
-                                                           solves_left, n_solves - 1, timed ? solve_start : nullptr, slot_of[0]}, d.N);
+                                                           solves_left, n_solves - 1, timed ? solve_start : nullptr, slot_of[0],
+                                                           trust_epilogue ? trust_ended_counts : nullptr}, d.N);
     if (!rollout_consistent) {
       launch_rollout_cost();
       rollout_consistent = true;
@@ -957,11 +991,12 @@ class SolverImpl final : public SolverBase {
                                 : launch_forward(fwd, forward_bytes() * kNumAlphas, nullptr, nullptr, std::numeric_limits<long long>::max());
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
-      const SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
-                           iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
-                           al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : list_next,
-                           n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
-                           debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr, trust_epilogue ? trust_ended : nullptr};
+      SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
+                     iters_total, exit_code, reinterpret_cast<int*>(ctr), ctr + 1, ctr_clear,
+                     al_round ? trial_obj : nullptr, al_round ? improvement : nullptr, al_round ? nullptr : list_next,
+                     n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
+                     debug ? dbg_iter : nullptr, debug ? dbg_improvement : nullptr, trust_epilogue ? trust_ended : nullptr};
+      if (trust_epilogue) { sel.ended_list = trust_ended_list; sel.ended_count = trust_ended_counts + (r & 1); sel.ended_clear = trust_ended_counts + ((r + 1) & 1); }
       be.template launch_1d<1>("select", sel, d.N);
       // the round's counters reach the host through the commit kernel (Publish); the multiplier update of constrained models
       // still changes them after the commit, so those rounds keep the copy
@@ -969,7 +1004,9 @@ class SolverImpl final : public SolverBase {
       if (poll) { pub = Publish{ctr, host_counters + 16 + (r % kCounterRing), 2}; pub.tag = static_cast<int>((r + 1) & 0x7FFF); }   // one packed word, polled by the host
       if (by_slot) be.template launch_2d<4>("commit", CommitSlotBody<M>{d, Xs, Us, alpha_sel, X, U, list_now, live, pub}, static_cast<int>(live_upper), d.T + 1);
       else be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
-      if (trust_epilogue) {
+      if (trust_epilogue && launch_trust_epilogue(trust_ended_counts + (r & 1))) {
+        // (one kernel: norm, re-roll by dependency levels, accept / revert and the copies, a workgroup per agent whose solve ended)
+      } else if (trust_epilogue) {
         const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
         be.template launch_1d<1>("trust_norm", TrustNormBody<M>{d, trust_ended, U, U_old, ts, trust_scale, trust_roll_list, trust_roll_count}, d.N);
         launch_trust_reroll(TrustRerollBody<M>{d, dt, P, x0, X, U, U_old, trust_scale, ts, trust_roll_list, trust_roll_count});
@@ -1186,6 +1223,7 @@ class SolverImpl final : public SolverBase {
   int *solves_left = nullptr;                         // chained solves an agent still has to run (run_sequential)
   int *trust_verdict = nullptr, *trust_ended = nullptr, *trust_roll_list = nullptr, *trust_roll_count = nullptr;   // chained trust-region epilogue
   double *trust_scale = nullptr;
+  int *trust_ended_list = nullptr, *trust_ended_counts = nullptr;   // agents whose solve ended in the round, compacted by select; two counters alternating by round
   unsigned long long* solve_start = nullptr;          // tick at which each agent's current solve began (finite max_ms only)
   int* dbg_iter = nullptr; double* dbg_improvement = nullptr;   // per-agent trace of the last round ("debug")
   unsigned long long* ladder_sync = nullptr;   // rung agreement of the centralised backward pass (LadderSync)

@@ -452,6 +452,11 @@ def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
     others = [old, unfused, fused_one_lane]
     if model == "MODEL_BICYCLE6":     # default here: a whole wavefront per agent in the backward pass; 32 lanes per agent; (old: 16)
         others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"backward_wave_max": 0}))
+    if strategy == "trustregion":     # round 4: the chained epilogue as one kernel (re-roll by dependency levels) against norm / re-roll / copy kernels
+        others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"trust_fused_max": 0}))
+        others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"trust_fused_max": 0, "trust_reroll_levels": 0}))   # (re-roll with four lanes per rollout)
+        others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"trust_fused_max": 0, "trust_reroll_levels": 0, "fused": 0, "forward_quad_max": 0}))
+        assert all(np.array_equal(new["radii"], other["radii"]) for other in others)
     for other in others:
         for key in ("cost", "X", "U", "iters", "status"):
             assert np.array_equal(new[key], other[key]), key

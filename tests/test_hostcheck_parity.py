@@ -3,11 +3,14 @@
 agreement is BIT-EXACT: costs, trajectories, iteration counts and regularisation events.
 The HIP build of the same sources is checked on the GPU by tests/test_gpu_parity.py."""
 import math
+import os
 
 import numpy as np
 import pytest
 
 from conftest import run_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _same(e, o, total_exact=True):
@@ -238,3 +241,13 @@ def test_centralized_dense_other_models_and_limits(hostcheck_lib, oracle):
     from multi_agent_solver_amd._capi import MasHipError
     with pytest.raises(MasHipError):                                      # 65 agents: beyond the literal solve's limit, loudly
         run_batch(hostcheck_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(65), None, 5, 0.5, "centralized_dense")
+
+
+def test_dependency_levels_of_the_vehicle_models(hostcheck_lib):
+    """mas_kernel_levels.hpp rolls an open-loop trajectory out level by level (all time steps of a level side by side, then serial
+    additions); that equals integrate_horizon bit for bit exactly when the levels the models declare (M::state_level) are true --
+    held here against the serial rollout on random trajectories, unknown components replaced by garbage."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "hostcheck", "build", "levels_check")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "levels_check: 0 mismatches" in r.stdout, (r.stdout, r.stderr)
