@@ -190,6 +190,8 @@ struct Publish {
   // converged}, the flag and the tag travel as ONE 64-bit store -- [tag:15][flag:1][converged:24][active:24] -- so the host can
   // never see a tag without its counters
   int tag = 0;
+  // centralised strategy (its host loop polls too): after the words, ONE more 64-bit store [poll_tag:32][..][flag:1][*poll_done != 0:1] to *poll_word
+  long long* poll_word = nullptr; int poll_tag = 0; const int* poll_done = nullptr;
   static constexpr int kTagShift = 49, kFlagShift = 48, kConvShift = 24; static constexpr long long kMask24 = 0xFFFFFF;
   MAS_HD static long long pack(int tag_, int flag_, long long conv, long long act) {
     return (static_cast<long long>(tag_ & 0x7FFF) << kTagShift) | (static_cast<long long>(flag_ != 0) << kFlagShift) | ((conv & kMask24) << kConvShift) | (act & kMask24);
@@ -198,6 +200,7 @@ struct Publish {
     if (tag != 0) { *reinterpret_cast<volatile long long*>(host) = pack(tag, flag ? *flag : 0, src[1], src[0] & 0xFFFFFFFFll); return; }
     for (int i = 0; i < words; ++i) host[i] = src[i];
     if (flag) host[words] = static_cast<long long>(*flag);
+    if (poll_word) *reinterpret_cast<volatile long long*>(poll_word) = (static_cast<long long>(poll_tag) << 32) | ((flag && *flag != 0) ? 2ll : 0ll) | ((poll_done && *poll_done != 0) ? 1ll : 0ll);
   }
 };
 

@@ -32,7 +32,9 @@ struct CentralState {
 
 #if !defined(MAS_HOST_EMULATION)
 // sum of v[0..n-1] in index order from 0.0 -- the serial loop's rounding -- by ONE wavefront: 64 values per coalesced load,
-// then added up lane by lane through v_readlane (a thread walking the array alone pays a full memory round trip per value).
+// then added up lane by lane through v_readlane_b32 pairs (a thread walking the array alone pays a full memory round trip per value;
+// __shfl with a constant lane compiles to ds_bpermute_b32 and a wait per element -- ~160 cycles per addition against ~20: the
+// centralised select took 17 us for ten sums of 256 costs).
 // Lanes beyond n contribute -0.0, which changes no bit of the running sum.  Every lane returns the sum.
 __device__ inline double wave_serial_sum(const double* v, int n) {
   const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -41,7 +43,10 @@ __device__ inline double wave_serial_sum(const double* v, int n) {
     double x[4];
     MAS_UNROLL for (int q = 0; q < 4; ++q) { const int a = base + 64 * q + lane; x[q] = a < n ? v[a] : -0.0; }
     MAS_UNROLL for (int q = 0; q < 4; ++q) {
-      if (base + 64 * q < n) { MAS_UNROLL for (int i = 0; i < 64; ++i) s += __shfl(x[q], i); }      // uniform
+      if (base + 64 * q < n) {                                           // uniform
+        const int lo32 = __double2loint(x[q]), hi32 = __double2hiint(x[q]);
+        MAS_UNROLL for (int i = 0; i < 64; ++i) s += __hiloint2double(__builtin_amdgcn_readlane(hi32, i), __builtin_amdgcn_readlane(lo32, i));
+      }
     }
   }
   return s;

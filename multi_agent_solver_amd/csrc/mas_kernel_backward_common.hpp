@@ -97,6 +97,7 @@ struct LadderSync {
   const int* live_list = nullptr; const int* live_count = nullptr;
   int xcd_stride = 1;                    // pipelined kernel: 8 = only every eighth workgroup works (the others exit at once), which puts all working workgroups on ONE XCD (workgroups are dealt round-robin over the 8 XCDs; tools/ubench/xcd_barrier.hip checks that through HW_REG_XCC_ID): their arrive-and-wait then stays inside one L2 (0.72 against 0.87 us bare).  Placement only -- the agreement is correct wherever the workgroups run
   int combine = 1;                       // workgroups of several wavefronts: combine their masks through LDS and arrive once per workgroup (measured on C2, us per pass: 245 against 546 when each of the 64 wavefronts arrives itself; single-wavefront workgroups: 253)
+  int peek = 1;                          // pipelined kernel: request the agreement word between the halves of the speculative step (ladder_peek)
   static constexpr int kChunks = 32, kArrivalShift = 32;
 };
 __device__ inline void ladder_post(const LadderSync& sy, int slot, unsigned wave_ok_mask) {
@@ -107,13 +108,19 @@ __device__ inline void ladder_post(const LadderSync& sy, int slot, unsigned wave
     __hip_atomic_fetch_add(w, 1ull << LadderSync::kArrivalShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ inline unsigned ladder_wait(const LadderSync& sy, int slot, int n_waves) {
+// first: a value of the word that was requested EARLIER (ladder_peek: its round trip to L2 has passed behind other work); 0 = none.
+// A complete counter in it settles the agreement without a poll.
+__device__ inline unsigned long long ladder_peek(const LadderSync& sy, int slot) {
+  return __hip_atomic_load(sy.words + static_cast<size_t>(slot) * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned ladder_wait(const LadderSync& sy, int slot, int n_waves, unsigned long long first = 0ull) {
   unsigned agreed = 0u;
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* w = sy.words + static_cast<size_t>(slot) * 4;
-    unsigned long long v = 0ull;
+    unsigned long long v = first;
     int spins = 0;
     for (;;) {
+      if (static_cast<int>(v >> LadderSync::kArrivalShift) == n_waves) break;
       v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (static_cast<int>(v >> LadderSync::kArrivalShift) == n_waves) break;
       if (++spins > (1 << 18) || __hip_atomic_load(sy.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicExch(sy.error, 1); break; }   // ~0.3 s, once per launch

@@ -436,6 +436,8 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   const double* tiles_0 = D + static_cast<size_t>(__builtin_amdgcn_readfirstlane(a0 / 64)) * 64 * ND;       // this wavefront's block of step 0 (uniform)
   auto fetch = [&](Tile& o, int t) {
     const double* tiles_t = tiles_0 + static_cast<size_t>(t) * step_doubles;
+    MAS_OPAQUE32(oAi); MAS_OPAQUE32(oAj); MAS_OPAQUE32(oBi); MAS_OPAQUE32(oBj);
+    MAS_OPAQUE32(olx); MAS_OPAQUE32(olu); MAS_OPAQUE32(olxx); MAS_OPAQUE32(olux); MAS_OPAQUE32(oluu);
     o.Ai[0] = ld2_off(tiles_t, oAi); o.Ai[1] = ld2_off(tiles_t, oAi + 16);
     o.Aj[0] = ld2_off(tiles_t, oAj); o.Aj[1] = ld2_off(tiles_t, oAj + 16);
     o.Bi[0] = ld2_off(tiles_t, oBi); o.Bi[1] = ld2_off(tiles_t, oBi + 16);
@@ -559,31 +561,40 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
     MAS_UNROLL for (int m = 0; m < NU; ++m) { unsigned o = koff[m]; MAS_OPAQUE32(o); st_off(Kfb_t, o, Ki[m]); }
   };
 
-  // the agreement, split in two: arrive (every wavefront / one per workgroup) and wait
+  // The agreement, split in two: arrive and wait.  In a workgroup of several wavefronts ONE wavefront (the last) posts the combined
+  // mask and ANOTHER (the first) reads the word, so that neither carries both on top of the common work: measured per step on C2,
+  // wave 0 spent 860 + 510 cycles around its atomics and its polls where the others spent 420 + 185, and everybody waits for the
+  // slowest at the workgroup barrier.
   const bool one_group = n_groups == 1;
+  const bool poster = (WPB == 1) || wave == WPB - 1, poller = ((WPB == 1) || wave == 0) && !one_group;
+  // combine the masks the wavefronts left in blk_field[buf] and post them (behind a barrier that follows their writes)
+  auto post_combined = [&](int word, unsigned buf) {
+    if (poster) {
+      unsigned bf = 0xFFFFu;
+      MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[buf][wv];
+      if (one_group) { if (tid == 0) blk_agreed[buf] = bf; }
+      else ladder_post(sync, word, bf);
+    }
+  };
   auto post = [&](int word, unsigned field) {
     if constexpr (WPB > 1) {
       if (tid == 0) blk_field[agreement_parity][wave] = field;
       __syncthreads();
-      if (wave == 0) {
-        unsigned bf = 0xFFFFu;
-        MAS_UNROLL for (int wv = 0; wv < WPB; ++wv) bf &= blk_field[agreement_parity][wv];
-        if (one_group) { if (tid == 0) blk_agreed[agreement_parity] = bf; }
-        else ladder_post(sync, word, bf);
-      }
+      post_combined(word, agreement_parity);
     } else {
       ladder_post(sync, word, field);
     }
   };
-  auto wait = [&](int word) -> unsigned {
+  // first: the word as ladder_peek returned it earlier (0: not requested)
+  auto wait = [&](int word, unsigned long long first = 0ull) -> unsigned {
     unsigned agreed;
     if constexpr (WPB > 1) {
-      if (wave == 0 && !one_group) { const unsigned g = ladder_wait(sync, word, n_groups); if (tid == 0) blk_agreed[agreement_parity] = g; }
+      if (poller) { const unsigned g = ladder_wait(sync, word, n_groups, first); if (tid == 0) blk_agreed[agreement_parity] = g; }
       __syncthreads();
       agreed = blk_agreed[agreement_parity];
       agreement_parity ^= 1u;
     } else {
-      agreed = ladder_wait(sync, word, n_groups);
+      agreed = ladder_wait(sync, word, n_groups, first);
     }
     return agreed;
   };
@@ -609,23 +620,56 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   // put them in scratch memory
   Tile tileA, tileB;
   Front frA, frB;
+  unsigned long long seen = 0ull;                               // the agreement word as requested early (written by that load alone: see below)
+#if defined(MAS_LADDER_STATS)
+  unsigned long long cy_back = 0, cy_front = 0, cy_wait = 0, cy_redo = 0, cy_post = 0, cy_top = 0, c_prev = __builtin_readcyclecounter(), st_redo = 0;
+#define MAS_LS(x) x
+#else
+#define MAS_LS(x)
+#endif
   // one step: `cur` = front(t) (settled, posted), `tile_next` holds tile t-1, `tile_refill` held tile t and is refilled with t-2
   auto iterate = [&](int t, int par, Front& cur, Front& nxt, Tile& tile_next, Tile& tile_refill) {
     if (t > 1) fetch(tile_refill, t - 2);                       // tile t is no longer needed (front(t) is settled): a whole step ahead of its use
     const bool speculate = (cur.field & 1u) != 0u;             // rung 0 works for every agent of this wavefront
+    MAS_LS(const unsigned long long c0 = __builtin_readcyclecounter(); unsigned long long c1 = c0; unsigned long long c2 = c0;)
+    // The agreement word of step t is REQUESTED between the two halves of the speculative work and looked at behind them: the
+    // other workgroups posted their masks of step t when this one did (~0.4 us to L2), so a load issued after back(t) usually
+    // returns the complete word while front(t-1) runs (98 of 100 steps on C2), and the step costs max(work, post + read)
+    // instead of work + read.  `seen` is written by that load alone and first touched behind front(t-1) (the empty asm pins
+    // that point): a clear or a select in between makes the compiler wait for EVERY load and store in flight -- the tile prefetch,
+    // the gain stores, and the atomics of the last post, whose acknowledgements then sit on the chain of every step.
     if (speculate) {
       back(t, par, cur, cur.Lcand, 0);
-      if (t > 0) front(tile_next, par ^ 1, nxt);
+      MAS_LS(c1 = __builtin_readcyclecounter();)
+      if (poller && sync.peek != 0) seen = ladder_peek(sync, t * LadderSync::kChunks);
+      if (t > 0) {
+        front(tile_next, par ^ 1, nxt);
+        // the mask of step t-1 goes to LDS at once: if the agreement of step t is rung 0 -- the common case -- the barrier inside wait()
+        // publishes it and the posting wavefront needs no barrier of its own
+        if constexpr (WPB > 1) { if (tid == 0) blk_field[agreement_parity ^ 1u][wave] = nxt.field; }
+      }
+      MAS_LS(c2 = __builtin_readcyclecounter();)
     }
-    const unsigned agreed = wait(t * LadderSync::kChunks);
+    asm volatile("" : "+v"(seen));
+    const unsigned agreed = wait(t * LadderSync::kChunks, (speculate && sync.peek != 0) ? seen : 0ull);
+    MAS_LS(const unsigned long long c3 = __builtin_readcyclecounter(); cy_back += c1 - c0; cy_front += c2 - c1; cy_wait += c3 - c2;)
     int win;
     if (agreed != 0u) win = __builtin_ctz(agreed); else settle_beyond(t, cur, win);
     if (!(speculate && win == 0)) {                             // not speculated, or speculated wrongly: the step with the agreed rung
+      MAS_LS(st_redo++;)
       back(t, par, cur, cur.Lcand, win & (LL - 1));
-      if (t > 0) front(tile_next, par ^ 1, nxt);
+      if (t > 0) {
+        front(tile_next, par ^ 1, nxt);
+        if constexpr (WPB > 1) { if (tid == 0) blk_field[agreement_parity][wave] = nxt.field; __syncthreads(); }
+      }
     }
     if (lane == 0 && a == 0) regs += win;                       // the stacked solve counts its rungs once (agent 0)
-    if (t > 0) post((t - 1) * LadderSync::kChunks, nxt.field);
+    MAS_LS(const unsigned long long c4 = __builtin_readcyclecounter();)
+    if (t > 0) {
+      if constexpr (WPB > 1) post_combined((t - 1) * LadderSync::kChunks, agreement_parity);
+      else ladder_post(sync, (t - 1) * LadderSync::kChunks, nxt.field);
+    }
+    MAS_LS(const unsigned long long c5 = __builtin_readcyclecounter(); cy_redo += c4 - c3; cy_post += c5 - c4; cy_top += c0 - c_prev; c_prev = c5;)
   };
   int t = d.T - 1;
   fetch(tileA, t);
@@ -635,6 +679,11 @@ mas_backward_row_pipelined_kernel(Dims d, ModelParams P, const double* __restric
   for (; t >= 1; t -= 2) { iterate(t, 0, frA, frB, tileB, tileA); iterate(t - 1, 1, frB, frA, tileA, tileB); }
   if (t == 0) iterate(0, 0, frA, frB, tileB, tileA);
   if (valid && lane == 0) reg_events[a] += regs;
+#if defined(MAS_LADDER_STATS)
+  if (tid == 0 && group == 0)
+    printf("cycles wave %d: top(fetch) %llu back %llu front %llu wait %llu redo %llu post %llu; redone %llu\n", wave, cy_top, cy_back, cy_front, cy_wait, cy_redo, cy_post, st_redo);
+#endif
+#undef MAS_LS
 }
 
 }  // namespace mas

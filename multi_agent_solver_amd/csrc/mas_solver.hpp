@@ -103,7 +103,7 @@ class SolverBase {
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
-    int central_combine = 1, central_wpb = kCentralWavesPerBlock;
+    int central_combine = 1, central_wpb = kCentralWavesPerBlock, central_peek = 1;
     bool set(const std::string& key, long long v) {
       if (key == "fused") fused = v != 0;
       else if (key == "forward_quad_max") forward_quad_max = v;
@@ -117,6 +117,7 @@ class SolverBase {
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
       else if (key == "central_combine") central_combine = static_cast<int>(v);
+      else if (key == "central_peek") central_peek = static_cast<int>(v);
       else if (key == "central_wpb") { if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) central_wpb = static_cast<int>(v); else return false; }
       else return false;
       return true;
@@ -124,7 +125,7 @@ class SolverBase {
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
       static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
-                                   "force_single_workgroup_central", "central_combine", "central_wpb"};
+                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
         for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
@@ -467,7 +468,6 @@ class SolverImpl final : public SolverBase {
     // the host runs one iteration AHEAD of the device: iteration r+1 is enqueued before the read-back of r is awaited; if r
     // turns out to have ended the solve, the kernels enqueued behind it find no active agent (CentralSelectBody::active).
     // A finite max_ms is checked at the top of every iteration (ilqr.hpp:84-90) and keeps the loop in step with the device.
-    if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
 #if defined(MAS_HOST_EMULATION)
     const bool run_ahead = false;
 #else
@@ -476,7 +476,11 @@ class SolverImpl final : public SolverBase {
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
     int enq = 0;
-    CentralState final_state{}; bool have_final = false, ladder_gave_up = false;
+    bool ladder_gave_up = false;
+    // the commit kernel of every iteration publishes the solve's state (host_central, read once when the loop has ended) and ONE word the
+    // host polls: [iteration + 1 : 32][gave up : 1][done : 1] -- no event between iterations (an event record costs ~5.5 us of idle device per iteration)
+    volatile long long* poll = host_counters + 24;
+    poll[0] = 0; poll[1] = 0;
     auto enqueue = [&]() {
       Marks& mk = marks[enq & 1];
       mk.p0 = be.mark(); mk.s0 = stamp_launches.size();
@@ -488,22 +492,32 @@ class SolverImpl final : public SolverBase {
       be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr}, d.N,
                       0.0, 0, std::max(64 * kNumAlphas, static_cast<int>((d.N + 63) / 64 * 64)));
       static_assert(sizeof(CentralState) % sizeof(long long) == 0, "published word by word");
-      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U,
-                               Publish{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long)),
-                                       ladder_error_flag()}}, d.N, d.T + 1);
-      be.record(round_ev[enq & 1]);
+      Publish pub{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long)),
+                  ladder_error_flag()};
+      pub.poll_word = host_counters + 24 + (enq & 1); pub.poll_tag = enq + 1; pub.poll_done = &central->done;
+      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
       ++enq;
+    };
+    auto await = [&](int r) -> long long {
+      const auto w0 = std::chrono::steady_clock::now();
+      for (long long spins = 1;; ++spins) {
+        const long long w = poll[r & 1];
+        if ((w >> 32) == r + 1) return w;
+        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 30.0) {
+          try { be.sync(); } catch (...) {}
+          throw std::runtime_error("the device did not publish an iteration of the centralised solve within 30 s");
+        }
+      }
     };
     if (max_iterations > 0) { if (timed_out(t0)) exit_reason = kExitTime; else enqueue(); }
     for (int r = 0; r < enq; ++r) {
       if (run_ahead && enq == r + 1 && enq < max_iterations) enqueue();
-      be.wait(round_ev[r & 1]);
+      const long long w = await(r);
       stats.agent_iterations += d.N;
       stats.batch_iterations++;
-      final_state = host_central[r & 1].st; have_final = true;
-      if (host_central[r & 1].ladder_error != 0) ladder_gave_up = true;
-      if (final_state.done) {
+      if (w & 2) ladder_gave_up = true;
+      if (w & 1) {
         exit_reason = kExitConverged;
         if (enq > r + 1) {                               // the iteration enqueued ahead runs on no agent: nothing to account
           be.scale_bytes(marks[(r + 1) & 1].p0, marks[(r + 1) & 1].p1, 0.0);
@@ -513,11 +527,13 @@ class SolverImpl final : public SolverBase {
       }
       if (enq == r + 1 && enq < max_iterations) { if (timed_out(t0)) { exit_reason = kExitTime; break; } enqueue(); }
     }
-    if (enq > 0) be.wait(round_ev[(enq - 1) & 1]);      // drain an iteration that ran ahead
+    be.sync();                                           // drains an iteration that ran ahead; the state below was published by the last commit
     if (ladder_gave_up) throw std::runtime_error("centralised backward pass: a wavefront gave up waiting for the rung agreement");   // (the flag is cleared with the words before every launch)
     // the state after the last executed iteration was published with it (an iteration enqueued behind the last one leaves it as it is);
     // only a solve without any iteration has to fetch what central_init wrote
-    if (!have_final) { be.d2h(&host_central[0].st, central, sizeof(CentralState)); final_state = host_central[0].st; }
+    CentralState final_state{};
+    if (enq > 0) final_state = host_central[(enq - 1) & 1].st;
+    else { be.d2h(&host_central[0].st, central, sizeof(CentralState)); final_state = host_central[0].st; }
     central_total = final_state.cur_total; last_total_valid = true;
     if (exit_reason == kExitConverged) stats.converged_solves += 1;
     fill_int(exit_code, exit_reason);
@@ -753,7 +769,7 @@ class SolverImpl final : public SolverBase {
       if (!ladder_sync) ladder_sync = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * (words + 2)));
       MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
       LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
-      sy.combine = switches.central_combine;
+      sy.combine = switches.central_combine; sy.peek = switches.central_peek;
       constexpr int apw = 64 / kLanes;
       be.begin("central_backward", bytes);
       const int wpb = central_waves_per_block();
@@ -762,7 +778,8 @@ class SolverImpl final : public SolverBase {
         const int groups = (d.N + agents_per_block - 1) / agents_per_block;
         // up to 32 working workgroups (one per CU of an XCD) are placed on ONE XCD by launching eight times as many and letting
         // every eighth work (LadderSync::xcd_stride); only the pipelined kernel knows the stride
-        sy.xcd_stride = (central_pipelined() && groups > 1 && groups <= 32 && central_one_xcd() && ladder_one_xcd_ok) ? 8 : 1;
+        // (a CU takes one wavefront per SIMD of this kernel: 32 CUs of an XCD hold 32 four-wavefront workgroups or 128 single-wavefront ones)
+        sy.xcd_stride = (central_pipelined() && groups > 1 && groups <= 32 * std::max(1, 4 / w) && central_one_xcd() && ladder_one_xcd_ok) ? 8 : 1;
         be.launch_kernel(kernel, dim3(groups * sy.xcd_stride), dim3(64 * w), d, P, X, D, kff, Kfb,
                          reg_events, active, 0, static_cast<int>(d.N), sy);
       };
@@ -1001,7 +1018,7 @@ class SolverImpl final : public SolverBase {
       // the round's counters reach the host through the commit kernel (Publish); the multiplier update of constrained models
       // still changes them after the commit, so those rounds keep the copy
       Publish pub = al_round ? Publish{} : Publish{ctr, host_counters + 2 * (r % kCounterRing), 2};
-      if (poll) { pub = Publish{ctr, host_counters + 16 + (r % kCounterRing), 2}; pub.tag = static_cast<int>((r + 1) & 0x7FFF); }   // one packed word, polled by the host
+      if (poll) { pub = Publish{ctr, host_counters + 16 + (r % kCounterRing), 2}; pub.tag = round_tag(r); }   // one packed word, polled by the host
       if (by_slot) be.template launch_2d<4>("commit", CommitSlotBody<M>{d, Xs, Us, alpha_sel, X, U, list_now, live, pub}, static_cast<int>(live_upper), d.T + 1);
       else be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
       if (trust_epilogue && launch_trust_epilogue(trust_ended_counts + (r & 1))) {
@@ -1060,15 +1077,19 @@ class SolverImpl final : public SolverBase {
   }
 
   // the packed word of round r (Publish::pack) in the pinned ring at host_counters[16 ..]: polled, not waited for with an event
-  long long await_round_word(long long r) const {
+  // 15-bit tag of round r, never 0 (0 is the cleared word, and Publish takes tag 0 for "no packed word"): 1 .. 0x7FFF, round after round
+  static int round_tag(long long r) { return 1 + static_cast<int>(r % 0x7FFF); }
+  long long await_round_word(long long r) {
     volatile long long* words = host_counters + 16;
-    const long long want = (r + 1) & 0x7FFF;
+    const long long want = round_tag(r);
     const auto t0 = std::chrono::steady_clock::now();
     for (long long spins = 1;; ++spins) {
       const long long w = words[r % kCounterRing];
       if (((w >> Publish::kTagShift) & 0x7FFF) == want) return w;
-      if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+      if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+        try { be.sync(); } catch (...) {}            // nothing of this call may still publish when a later call clears and reuses the words
         throw std::runtime_error("the device did not publish a round's counters within 30 s");
+      }
     }
   }
   void clear_round_words() const { volatile long long* words = host_counters + 16; for (int q = 0; q < kCounterRing; ++q) words[q] = 0; }
@@ -1118,7 +1139,7 @@ class SolverImpl final : public SolverBase {
       fr.error = fused_error;
       launch_fused(fr, fused_bytes());
       ForwardBody<M> fwd = fwd_proto;
-      if (r > 0) { fwd.publish = Publish{ctr_prev, host_counters + 16 + (r % kRing), 2, fused_error}; fwd.publish.tag = static_cast<int>((r + 1) & 0x7FFF); }
+      if (r > 0) { fwd.publish = Publish{ctr_prev, host_counters + 16 + (r % kRing), 2, fused_error}; fwd.publish.tag = round_tag(r); }
       const int* live = (r == 0) ? live_count0 : reinterpret_cast<const int*>(ctr_prev);
       by_slot[r & 1] = launch_forward(fwd, forward_bytes() * kNumAlphas, live_lists[r & 1], live, live_upper);
       mk.p1 = be.mark();
