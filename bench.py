@@ -46,7 +46,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r3"    # profiles/<round>_pmc_traffic_<workload>.json, profiles/<round>_sq_counters_<workload>.json
+FP64_PEAK_TFLOPS = 78.6 # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz), SURVEY.md 8(d)
+PROFILE_ROUND = "r4"    # profiles/<round>_pmc_traffic_<workload>.json, profiles/<round>_sq_counters_<workload>.json
+
+
+def backward_flops_per_step(nx, nu):
+    """FP64 operations of one backward Riccati step (ilqr.hpp:115-119,183-192) counted on the dense products: SURVEY.md 8(d) quotes ~700 at (4, 2)"""
+    return (4 * nx ** 3 + 4 * nx * nx * nu + 2 * nx * nu * nu + 2 * nx * nx + 2 * nx * nu      # A^T V A, B^T V A, B^T V B, q_x, q_u
+            + nu ** 3 // 3 + nu ** 3 + 4 * nu * nu * nx + 2 * nu * nu                         # LLT, its inverse, K, k, K^T q_uu
+            + 6 * nx * nu + 6 * nx * nx * nu + nx * nx)                                        # v_x, v_xx, symmetrisation
 
 
 from multi_agent_solver_amd.dist import shard_range  # noqa: E402  contiguous ranges of the id-sorted block list, one per rank
@@ -56,16 +64,21 @@ M_SINGLE_TRACK, M_LQR, M_BICYCLE6 = 1, 2, 5
 WORKLOADS = {
     "c3": dict(name="multi_agent_single_track --solver ilqr --strategy sequential, 4096 agents per GPU, H=100 (BASELINE configs[2])",
                model=M_SINGLE_TRACK, nx=4, nu=2, agents=4096, T=100, dt=0.5, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=51392, backward_bytes_per_agent=54432),
+               sweep_bytes_per_agent=51392, backward_bytes_per_agent=54432,
+               # per (agent, t) 12 dynamics evaluations x ~150 + 118 cost evaluations x ~25 FP64 operations = 4.8e5 per agent-iteration at T = 100
+               sweep_flops_per_agent=100 * (12 * 150 + 118 * 25), forward_flops_per_agent_trial=100 * (4 * 150 + 25 + 30)),
     "c2": dict(name="multi_agent_single_track --solver ilqr --strategy centralized, 256 agents, H=100 (BASELINE configs[1])",
                model=M_SINGLE_TRACK, nx=4, nu=2, agents=256, T=100, dt=0.5, strategy="centralized", max_outer=1, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=51392, backward_bytes_per_agent=54432),
+               sweep_bytes_per_agent=51392, backward_bytes_per_agent=54432,
+               sweep_flops_per_agent=100 * (12 * 150 + 118 * 25), forward_flops_per_agent_trial=100 * (4 * 150 + 25 + 30)),
     "c4": dict(name="multi_agent_lqr --solver ilqr --strategy sequential, 4096 agents per GPU (32768 on 8), H=50 (BASELINE configs[3])",
                model=M_LQR, nx=4, nu=4, agents=4096, T=50, dt=0.1, strategy="sequential", max_outer=10, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=38592, backward_bytes_per_agent=8 * 50 * 88 + 32 + 8 * 50 * 20),
+               sweep_bytes_per_agent=38592, backward_bytes_per_agent=8 * 50 * 88 + 32 + 8 * 50 * 20,
+               sweep_flops_per_agent=50 * 16, forward_flops_per_agent_trial=50 * (4 * 8 + 16 + 40)),       # analytic derivatives (2x, 2u), x' = x + u
     "c5": dict(name="multi_agent_single_track --solver ilqr --strategy trustregion, nx=6 bicycle model, 8192 agents per GPU (65536 on 8), H=200 (BASELINE configs[4])",
                model=M_BICYCLE6, nx=6, nu=2, agents=8192, T=200, dt=0.25, strategy="trustregion", max_outer=10, max_iterations=100, tolerance=1e-5,
-               sweep_bytes_per_agent=185984, backward_bytes_per_agent=8 * 200 * 108 + 48 + 8 * 200 * 14),
+               sweep_bytes_per_agent=185984, backward_bytes_per_agent=8 * 200 * 108 + 48 + 8 * 200 * 14,
+               sweep_flops_per_agent=200 * (16 * 160 + 216 * 30), forward_flops_per_agent_trial=200 * (4 * 160 + 30 + 40)),   # 16 dynamics + 216 cost evaluations per (agent, t)
 }
 
 
@@ -282,24 +295,70 @@ ROOFLINE_KERNELS = {
 }
 
 
+def _issue_fill(workload, name):
+    """share of the chip's FP64 issue slots a kernel fills (SQ_ACTIVE_INST_VALU over all SIMDs' cycles of the kernel's launches), from the committed
+    rocprofv3 --pmc SQ passes; (None, reason) without counters collected from exactly these kernel sources"""
+    sq, src = _load_profile("sq_counters", workload)
+    if not sq:
+        return None, src
+    k = sq.get("kernels", {}).get(name, {}).get("derived", {})
+    if "chip_valu_busy_pct" not in k:
+        return None, f"{src}: no such kernel in the profile"
+    return k["chip_valu_busy_pct"] / 100.0, f"derived: {src} (SQ_ACTIVE_INST_VALU / (kernel time x 1024 SIMDs), source_hash {sq.get('source_hash')})"
+
+
+def fp64_block(k, agent_launches, flops_per_agent_launch, workload, name, what):
+    """nominal FP64 operations (evaluation counts x operations per evaluation, dense-product counts for the recursion) / kernel time
+    against the FP64 vector peak, and the measured issue fill next to it.  The nominal count is NOT the executed instruction count: the
+    compiler merges the common subexpressions of the 130 perturbed evaluations of a sweep item, and the
+    reference's arithmetic forbids FMA contraction, so one issued instruction is one operation, not two."""
+    tf = agent_launches * flops_per_agent_launch / (k["total_ms"] * 1e-3) / 1e12
+    fill, fill_src = _issue_fill(workload, name)
+    return dict(achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS, flops_per_agent_launch=flops_per_agent_launch,
+                flops_note=what, issue_fill=fill, issue_fill_source=fill_src)
+
+
+def round_fill_of(kt, workload):
+    """time-weighted FP64 issue fill over the two serial chains of a round (recursion kernel + line search): how full the chip is while
+    the run's critical path executes; null without SQ counters collected from these kernel sources"""
+    chain = [n for n in ("linearise_riccati", "backward", "central_backward", "forward") if kt.get(n, {}).get("total_ms", 0) > 0]
+    parts, tot, acc = {}, 0.0, 0.0
+    for n in chain:
+        fill, src = _issue_fill(workload, n)
+        if fill is None:
+            return dict(value=None, reason=src)
+        parts[n] = dict(ms=round(kt[n]["total_ms"], 4), issue_fill=fill)
+        tot += kt[n]["total_ms"]; acc += kt[n]["total_ms"] * fill
+    return dict(value=(acc / tot if tot > 0 else None), kernels=parts, what="sum(kernel time x issue fill) / sum(kernel time) over the chain kernels of the instrumented pass")
+
+
 def roofline_of(kt, w, workload, name=None):
-    """achieved = algorithmic bytes (SURVEY.md 8(d) per agent x active agents of each launch) / launch durations.
-    Kernel: the fused linearise + Riccati kernel where the round is fused (four-state models), else the linearisation sweep.
-    `frac` uses the HIP events bound to each dispatch of the instrumented pass (every launch of the kernel) -- the quantity
-    rocprofv3 --kernel-trace averages, so profiles/*_kernel_stats.csv can be held against it.  `inkernel_span` (sweep only) is
-    the same sum over the kernel's own first-workgroup-start .. last-workgroup-end REFCLK stamps (no dispatch ramp)."""
+    """The contract's figure: achieved = algorithmic bytes (SURVEY.md 8(d) per agent x active agents of each launch) / launch durations, against
+    the HBM peak.  Kernel: the fused linearise + Riccati kernel where the round is fused (four-state models), else the linearisation sweep.
+    `frac` uses the HIP events bound to each dispatch of the instrumented pass (every launch of the kernel) -- the quantity rocprofv3
+    --kernel-trace averages, so profiles/*_kernel_stats.csv can be held against it.  `bound` says what ACTUALLY limits the kernel: the sweep
+    kernel streams its tiles to HBM ("hbm"); the fused kernel keeps them in LDS and is limited by the recursion's dependent FP64 chain
+    ("fp64_issue") -- for it `frac` is the equivalent throughput of an unfused implementation, `hbm_measured` the HBM utilisation from the PMC
+    byte counters and `fp64` the figure against the limit that binds.  `inkernel_span` (sweep only) is the same sum over the kernel's own
+    first-workgroup-start .. last-workgroup-end REFCLK stamps (no dispatch ramp)."""
     if name is None:
         name = "linearise_riccati" if kt.get("linearise_riccati", {}).get("launches") else "sweep"
     k = kt.get(name)
     if not k or k["launches"] == 0 or k["total_ms"] <= 0:
         return None
     symbol, what, bound_by = ROOFLINE_KERNELS[name]
+    fused = name == "linearise_riccati"
+    bytes_per_agent = (w["sweep_bytes_per_agent"] + w["backward_bytes_per_agent"]) if fused else w["sweep_bytes_per_agent"]
+    agent_launches = k["algorithmic_bytes"] / bytes_per_agent            # sum over launches of the agents active in them
     achieved = k["algorithmic_bytes"] / (k["total_ms"] * 1e-3) / 1e9
-    out = dict(bound="hbm", kernel=symbol, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+    out = dict(bound=("fp64_issue" if fused else "hbm"), kernel=symbol, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+               frac_is=("equivalent unfused throughput: SURVEY.md 8(d)'s sweep + backward bytes / kernel time / HBM peak -- the contract's figure; the tiles stay in LDS, "
+                        "so this is NOT the kernel's HBM utilisation (hbm_measured) and NOT what binds it (fp64)" if fused else
+                        "SURVEY.md 8(d)'s sweep bytes / kernel time / HBM peak: the kernel streams these bytes, hbm_measured agrees with it to a few per cent"),
                timing="HIP events bound to each dispatch (hipExtLaunchKernelGGL), all launches of the instrumented pass",
                launches=k["launches"], avg_launch_us=1e3 * k["total_ms"] / k["launches"],
                algorithmic_bytes_per_launch=k["algorithmic_bytes"] / k["launches"],
-               algorithmic_bytes_per_agent=(w["sweep_bytes_per_agent"] + w["backward_bytes_per_agent"]) if name == "linearise_riccati" else w["sweep_bytes_per_agent"],
+               algorithmic_bytes_per_agent=bytes_per_agent,
                algorithmic_bytes_note=what, limited_by=bound_by)
     ik = kt.get(name + "_inkernel")
     if ik and ik["launches"] and ik["total_ms"] > 0:
@@ -315,12 +374,26 @@ def roofline_of(kt, w, workload, name=None):
     # prescribes: FETCH_SIZE x2 on gfx950) applied to this run's algorithmic bytes per launch.  null (with the reason) without a
     # profile collected from exactly these kernel sources.
     pmc, src = _load_profile("pmc_traffic", workload)
-    out["traffic"], out["traffic_source"] = None, src
+    out["traffic"], out["traffic_source"], out["hbm_measured"] = None, src, None
     if pmc and name in pmc.get("kernels", {}):
         ratio = pmc["kernels"][name].get("measured_over_algorithmic")
         if ratio:
             out["traffic"] = ratio * out["algorithmic_bytes_per_launch"]
             out["traffic_source"] = f"derived: {src} (FETCH_SIZE x2 + WRITE_SIZE = {ratio:.4f} x algorithmic bytes over the launches of one strategy run; collected at {pmc.get('commit', 'unknown commit')}, source_hash {pmc.get('source_hash')})"
+            out["hbm_measured"] = dict(achieved=ratio * achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=ratio * achieved / HBM_PEAK_GBS,
+                                       what="HBM bytes of the PMC counters / kernel time: the kernel's actual HBM utilisation")
+    # against the limit that binds the fused kernel (and, for reference, the sweep): nominal FP64 operations / time / vector peak + measured issue fill
+    flops = w["sweep_flops_per_agent"] + (w["T"] * backward_flops_per_step(w["nx"], w["nu"]) if fused else 0)
+    out["fp64"] = fp64_block(k, agent_launches, flops, workload, name,
+                             "SURVEY.md 8(d): linearisation (evaluation counts x operations per evaluation)" + (" + backward recursion (dense products of ilqr.hpp:115-119,183-192)" if fused else ""))
+    fw = kt.get("forward")
+    if fw and fw["launches"] and fw["total_ms"] > 0:
+        NUM_ALPHAS = 10          # alpha = 1, 1/2, ... >= 1e-3 (ilqr.hpp:199-206): kNumAlphas, csrc/mas_bodies.hpp
+        out["line_search"] = dict(bound="fp64_issue", kernel="ForwardBody / mas_forward_quad_kernel", launches=fw["launches"], avg_launch_us=1e3 * fw["total_ms"] / fw["launches"],
+                                  limited_by="the rollout's dependent FP64 chain (T steps per trial; ten trials side by side)",
+                                  fp64=fp64_block(fw, agent_launches, NUM_ALPHAS * w["forward_flops_per_agent_trial"], workload, "forward",
+                                                  "ten trial rollouts per agent and launch: T x (4 dynamics evaluations + stage cost + feedback law)"))
+    out["round_fill"] = round_fill_of(kt, workload)
     return out
 
 

@@ -204,7 +204,18 @@ int mas_hip_comm_unique_id(void* id_out /* MAS_HIP_COMM_ID_BYTES */);           
 int mas_hip_comm_create(const void* id, int n_ranks, int rank, int device, mas_hip_comm** out);     /* ncclCommInitRank (collective over the ranks) */
 int mas_hip_comm_create_all(int n_devices, const int* devices, mas_hip_comm** out /* [n_devices] */);   /* ncclCommInitAll: one process, several GPUs */
 int mas_hip_comm_destroy(mas_hip_comm*);
+/* a rank that cannot go on (upload failed, handle refused, solve gave up) releases every peer that waits for it inside a collective
+ * (ncclCommAbort).  May be called from another thread than the one driving the rank; every later collective on the communicator
+ * fails at once; the object stays valid until mas_hip_comm_destroy.  mas_amd's sharded strategies abort ALL communicators of the
+ * group from the failing shard's thread. */
+int mas_hip_comm_abort(mas_hip_comm*);
 const char* mas_hip_comm_last_error(void);
+/* Communicators made AFTER this call use the in-process LOOPBACK transport instead of librccl (0: back to librccl): ranks are host
+ * threads of this process, collectives a rendezvous and copies between the ranks' buffers.  Not a product path -- it exists so that
+ * the multi-rank logic of this section (shard displacements, even and uneven; grouped broadcasts; the line search's total over all
+ * ranks) runs with several ranks where RCCL cannot: without a second GPU, with several shards on one GPU (tests/test_loopback_ranks.py,
+ * tests/test_gpu_rccl.py).  The multi-rank entry points have run over librccl itself with ONE rank only so far. */
+int mas_hip_comm_use_loopback(int enabled);
 void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi);                       /* contiguous id ranges, sizes differ by at most one */
 int mas_hip_all_gather_solution(mas_hip_solver*, mas_hip_comm*, int n_total, void* X_all_dev, void* U_all_dev, void* cost_all_dev);   /* any buffer may be NULL */
 int mas_hip_set_comm_cost_exchange(mas_hip_solver*, mas_hip_comm* /* NULL: local sum */, int n_total);

@@ -29,7 +29,7 @@ EXPORTS = [
     "mas_hip_get_solution_host", "mas_hip_get_solution_device", "mas_hip_total_cost",
     "mas_hip_set_cost_exchange", "mas_hip_get_trust_radii_host", "mas_hip_debug_backward_host",
     "mas_hip_get_stats", "mas_hip_reset_stats", "mas_hip_set_profiling", "mas_hip_get_kernel_times",
-    "mas_hip_comm_unique_id", "mas_hip_comm_create", "mas_hip_comm_create_all", "mas_hip_comm_destroy", "mas_hip_comm_last_error",
+    "mas_hip_comm_unique_id", "mas_hip_comm_create", "mas_hip_comm_create_all", "mas_hip_comm_destroy", "mas_hip_comm_abort", "mas_hip_comm_use_loopback", "mas_hip_comm_last_error",
     "mas_hip_shard_range", "mas_hip_all_gather_solution", "mas_hip_set_comm_cost_exchange",
 ]
 
@@ -128,6 +128,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     lib.mas_hip_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.mas_hip_comm_create_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.mas_hip_comm_destroy.argtypes = [vp]
+    lib.mas_hip_comm_abort.argtypes = [vp]
+    lib.mas_hip_comm_use_loopback.argtypes = [C.c_int]
     lib.mas_hip_comm_last_error.restype = C.c_char_p
     lib.mas_hip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mas_hip_shard_range.restype = None

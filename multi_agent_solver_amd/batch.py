@@ -33,15 +33,40 @@ class Comm:
     the 128 bytes to the others by any channel (torch.distributed broadcast, a file, MPI), then `Comm(id, n_ranks, rank, device)`
     on every rank (collective)."""
 
-    def __init__(self, unique_id: bytes, n_ranks: int, rank: int, device: int = 0, lib=None):
+    def __init__(self, unique_id: bytes, n_ranks: int, rank: int, device: int = 0, lib=None, _handle=None):
         self._lib = lib or _capi.product_lib()
         self.n_ranks, self.rank, self.device = n_ranks, rank, device
+        if _handle is not None:                     # made by create_all
+            self._h = _handle
+            return
         buf = C.create_string_buffer(bytes(unique_id), 128)
         h = C.c_void_p()
         rc = self._lib.mas_hip_comm_create(C.cast(buf, C.c_void_p), n_ranks, rank, device, C.byref(h))
         if rc != _capi.OK:
             raise _capi.MasHipError(rc, (self._lib.mas_hip_comm_last_error() or b"").decode())
         self._h = h
+
+    @staticmethod
+    def create_all(devices, lib=None):
+        """mas_hip_comm_create_all (ncclCommInitAll): one process, one communicator per entry of `devices`, each to be driven from its own thread"""
+        lib = lib or _capi.product_lib()
+        n = len(devices)
+        devs = (C.c_int * n)(*devices)
+        out = (C.c_void_p * n)()
+        rc = lib.mas_hip_comm_create_all(n, devs, out)
+        if rc != _capi.OK:
+            raise _capi.MasHipError(rc, (lib.mas_hip_comm_last_error() or b"").decode())
+        return [Comm(b"", n, r, devices[r], lib=lib, _handle=C.c_void_p(out[r])) for r in range(n)]
+
+    @staticmethod
+    def use_loopback(enabled: bool, lib=None):
+        """communicators made after this call use the in-process loopback transport (tests; include/mas_hip.h)"""
+        (lib or _capi.product_lib()).mas_hip_comm_use_loopback(1 if enabled else 0)
+
+    def abort(self):
+        """release every peer waiting for this rank inside a collective (ncclCommAbort); later collectives fail at once; close() still frees it"""
+        if self._h:
+            self._lib.mas_hip_comm_abort(self._h)
 
     @staticmethod
     def unique_id(lib=None) -> bytes:

@@ -36,7 +36,7 @@ using Stream = void*;
 #define MAS_ATOMIC_ADD_I64(ptr, v) (*(ptr) += (v))
 
 struct Backend {
-  Stream stream = nullptr;
+  Stream stream = nullptr, cur = nullptr;
   bool profiling = false;
   std::map<std::string, KernelStat> stats;
 

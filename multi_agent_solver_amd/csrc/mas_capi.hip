@@ -10,11 +10,7 @@
 
 #include "mas_solver.hpp"
 
-#if !defined(MAS_HOST_EMULATION)
 struct mas_hip_comm { mas::Comm c; };
-#else
-struct mas_hip_comm { int unused; };
-#endif
 
 struct mas_hip_solver {
   std::unique_ptr<mas::SolverBase> impl;
@@ -72,7 +68,6 @@ int create_impl(const mas_hip_problem_desc* desc, void* stream, mas_hip_solver**
   }
 }
 thread_local std::string g_comm_error;
-#if !defined(MAS_HOST_EMULATION)
 template <class Fn>
 int comm_guarded(Fn&& fn) {
   try {
@@ -83,7 +78,13 @@ int comm_guarded(Fn&& fn) {
   } catch (const std::invalid_argument& e) { g_comm_error = e.what(); return MAS_HIP_ERR_INVALID;
   } catch (const std::exception& e) { g_comm_error = e.what(); return MAS_HIP_ERR_RUNTIME; }
 }
+void select_device(int device) {
+#if !defined(MAS_HOST_EMULATION)
+  MAS_HIP_CHECK(hipSetDevice(device));
+#else
+  (void)device;
 #endif
+}
 }  // namespace
 
 extern "C" {
@@ -153,9 +154,9 @@ int mas_hip_total_cost(mas_hip_solver* h, double* total) {
 int mas_hip_set_cost_exchange(mas_hip_solver* h, mas_hip_cost_exchange_fn fn, void* ctx) {
   return guarded(h, [&](mas::SolverBase& s) { s.cost_exchange = fn; s.cost_exchange_ctx = ctx; });
 }
-#if !defined(MAS_HOST_EMULATION)
-// ---- RCCL communicators (mas_rccl.hpp) ----
+// ---- communicators (mas_rccl.hpp): librccl, or the in-process loopback transport when it was selected ----
 const char* mas_hip_comm_last_error(void) { return g_comm_error.c_str(); }
+int mas_hip_comm_use_loopback(int enabled) { mas::RcclApi::use_loopback(enabled != 0); return MAS_HIP_OK; }
 int mas_hip_comm_unique_id(void* id_out) {
   if (!id_out) return MAS_HIP_ERR_INVALID;
   return comm_guarded([&](mas::RcclApi& api) {
@@ -169,34 +170,45 @@ int mas_hip_comm_create(const void* id, int n_ranks, int rank, int device, mas_h
   if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MAS_HIP_ERR_INVALID;
   *out = nullptr;
   return comm_guarded([&](mas::RcclApi& api) {
-    MAS_HIP_CHECK(hipSetDevice(device));
+    select_device(device);
     mas::ncclUniqueId uid;
     std::memcpy(uid.internal, id, sizeof(uid.internal));
     auto c = std::make_unique<mas_hip_comm>();
-    c->c.n_ranks = n_ranks; c->c.rank = rank; c->c.device = device;
+    c->c.n_ranks = n_ranks; c->c.rank = rank; c->c.device = device; c->c.api = &api;
     c->c.check(api.CommInitRank(&c->c.comm, n_ranks, uid, rank), "ncclCommInitRank");
     *out = c.release();
   });
 }
 int mas_hip_comm_create_all(int n_devices, const int* devices, mas_hip_comm** out) {
   if (!out || n_devices < 1) return MAS_HIP_ERR_INVALID;
+  for (int i = 0; i < n_devices; ++i) out[i] = nullptr;
   return comm_guarded([&](mas::RcclApi& api) {
     std::vector<int> devs(n_devices);
     for (int i = 0; i < n_devices; ++i) devs[i] = devices ? devices[i] : i;
     std::vector<mas::ncclComm_t> comms(n_devices, nullptr);
-    mas::Comm probe;
+    mas::Comm probe; probe.api = &api;
     probe.check(api.CommInitAll(comms.data(), n_devices, devs.data()), "ncclCommInitAll");
     for (int i = 0; i < n_devices; ++i) {
       out[i] = new mas_hip_comm();
-      out[i]->c.comm = comms[i]; out[i]->c.n_ranks = n_devices; out[i]->c.rank = i; out[i]->c.device = devs[i];
+      out[i]->c.comm = comms[i]; out[i]->c.n_ranks = n_devices; out[i]->c.rank = i; out[i]->c.device = devs[i]; out[i]->c.api = &api;
     }
   });
 }
 int mas_hip_comm_destroy(mas_hip_comm* c) {
   if (!c) return MAS_HIP_ERR_INVALID;
-  const int rc = comm_guarded([&](mas::RcclApi& api) { if (c->c.comm) c->c.check(api.CommDestroy(c->c.comm), "ncclCommDestroy"); });
+  int rc = MAS_HIP_OK;
+  try { if (c->c.comm) c->c.check(c->c.table().CommDestroy(c->c.comm), "ncclCommDestroy"); }
+  catch (const std::exception& e) { g_comm_error = e.what(); rc = MAS_HIP_ERR_RUNTIME; }
   delete c;
   return rc;
+}
+// a rank that cannot go on (its upload failed, its handle was refused, its solve gave up) releases every peer that waits for it in
+// a collective -- ncclCommAbort; may be called from another thread than the one driving the rank; the object stays valid (every
+// later collective on it fails at once) until mas_hip_comm_destroy
+int mas_hip_comm_abort(mas_hip_comm* c) {
+  if (!c) return MAS_HIP_ERR_INVALID;
+  try { c->c.abort(); return MAS_HIP_OK; }
+  catch (const std::exception& e) { g_comm_error = e.what(); return MAS_HIP_ERR_RUNTIME; }
 }
 void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi) {
   int a = 0, b = 0;
@@ -207,28 +219,13 @@ void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi) {
 int mas_hip_all_gather_solution(mas_hip_solver* h, mas_hip_comm* c, int n_total, void* X_all, void* U_all, void* cost_all) {
   if (!c) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) {
-    if (!mas::RcclApi::get().ok()) throw std::runtime_error("librccl not available: " + mas::RcclApi::get().error);
+    if (!c->c.table().ok()) throw std::runtime_error("librccl not available: " + c->c.table().error);
     s.all_gather_solution(&c->c, n_total, static_cast<double*>(X_all), static_cast<double*>(U_all), static_cast<double*>(cost_all));
   });
 }
 int mas_hip_set_comm_cost_exchange(mas_hip_solver* h, mas_hip_comm* c, int n_total) {
   return guarded(h, [&](mas::SolverBase& s) { s.set_comm_exchange(c ? &c->c : nullptr, n_total); });
 }
-#else   // host emulation (tests/hostcheck): no devices, no RCCL
-const char* mas_hip_comm_last_error(void) { return "no RCCL in the host emulation"; }
-int mas_hip_comm_unique_id(void*) { return MAS_HIP_ERR_RUNTIME; }
-int mas_hip_comm_create(const void*, int, int, int, mas_hip_comm**) { return MAS_HIP_ERR_RUNTIME; }
-int mas_hip_comm_create_all(int, const int*, mas_hip_comm**) { return MAS_HIP_ERR_RUNTIME; }
-int mas_hip_comm_destroy(mas_hip_comm*) { return MAS_HIP_ERR_RUNTIME; }
-void mas_hip_shard_range(int n_total, int n_ranks, int rank, int* lo, int* hi) {
-  const int base = n_ranks > 0 ? n_total / n_ranks : 0, extra = n_ranks > 0 ? n_total % n_ranks : 0;
-  const int a = rank * base + (rank < extra ? rank : extra);
-  if (lo) *lo = a;
-  if (hi) *hi = a + base + (rank < extra ? 1 : 0);
-}
-int mas_hip_all_gather_solution(mas_hip_solver*, mas_hip_comm*, int, void*, void*, void*) { return MAS_HIP_ERR_RUNTIME; }
-int mas_hip_set_comm_cost_exchange(mas_hip_solver*, mas_hip_comm*, int) { return MAS_HIP_ERR_RUNTIME; }
-#endif
 int mas_hip_get_trust_radii_host(mas_hip_solver* h, double* radii) {
   if (!radii) return MAS_HIP_ERR_INVALID;
   return guarded(h, [&](mas::SolverBase& s) { s.get_trust_radii(radii); });

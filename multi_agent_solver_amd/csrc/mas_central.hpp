@@ -55,13 +55,13 @@ __device__ inline double wave_serial_sum(const double* v, int n) {
 
 // total cost of all agents + the decision of one stage of the Nash line search (JointState, mas_bodies.hpp); one wavefront
 struct JointSumBody {
-  enum Mode : int { kBase = 0, kAfterSolves = 1, kAfterTrial = 2 };
+  enum Mode : int { kBase = 0, kAfterSolves = 1, kAfterTrial = 2, kFinal = 3 /* the Solution's total cost: the sum only, no decision */ };
   const double* costs; int n; JointState* st; int mode;
   MAS_HD void decide(double s) const {
     st->last_total = s;
     if (mode == kBase) { st->base = s; st->need_blend = 0; st->accepted = 0; }
     else if (mode == kAfterSolves) { st->accepted = 0; if (s >= st->base) st->need_blend = 1; else { st->base = s; st->need_blend = 0; } }   // nash.hpp:119-123,178
-    else if (st->need_blend && !st->accepted && s < st->base) { st->base = s; st->accepted = 1; }                                               // nash.hpp:144-158
+    else if (mode == kAfterTrial && st->need_blend && !st->accepted && s < st->base) { st->base = s; st->accepted = 1; }                       // nash.hpp:144-158
   }
 #if defined(MAS_HOST_EMULATION)
   void run_serial(int) const {

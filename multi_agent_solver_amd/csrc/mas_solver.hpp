@@ -21,10 +21,10 @@
 #include "mas_bodies.hpp"
 #include "mas_central.hpp"
 #include "mas_dense.hpp"
+#include "mas_rccl.hpp"
 #if !defined(MAS_HOST_EMULATION)
 #include "mas_kernels_hip.hpp"
 #include "mas_fused_hip.hpp"
-#include "mas_rccl.hpp"
 #endif
 
 namespace mas {
@@ -336,7 +336,11 @@ class SolverImpl final : public SolverBase {
     // whose solve ends runs its epilogue in that round (TrustNormBody / TrustRerollBody / TrustCopyBody) and starts its
     // next solve in the following one -- no host barrier, no waiting for the slowest agent of every outer iteration.  The
     // multiplier update between solves and the per-agent debug trace need the host between solves and keep the loop.
-    const bool chain = max_outer > 1 && !(kConstrained && al_enabled) && !debug;
+    // (a solve that cannot run an iteration -- max_iterations 0 or a negative time budget -- enqueues no round and with it no
+    // epilogue: those cases take the loop below, whose trust-region test follows every solve as a kernel of its own; found by
+    // holding the radii against the oracle's in round 4: 0.5^max_outer there, 1.0 here before)
+    const bool no_iteration = max_iterations <= 0 || (max_ms < std::numeric_limits<double>::infinity() && 0.0 > max_ms);
+    const bool chain = max_outer > 1 && !(kConstrained && al_enabled) && !debug && !no_iteration;
     if (chain) {
       snapshot_old();
       solve_all(max_outer, /*trust_epilogue=*/true);
@@ -375,7 +379,11 @@ class SolverImpl final : public SolverBase {
       }
       be.template launch_2d<4>("revert", RevertBody<M>{d, joint, X, U, cost, X_old, U_old, cost_old}, d.N, d.T + 1);
     }
-    last_total_valid = false;
+    // Solution.total_cost (collect_solution, nash.hpp:23-37): the sum over ALL agents in block order -- with the block list sharded over
+    // ranks that is every rank's agents, formed like the totals the strategy decided on (one more all-gather + serial sum)
+    joint_sum_device(JointSumBody::kFinal);
+    be.d2h(host_joint, joint, sizeof(JointState));
+    central_total = host_joint->last_total; last_total_valid = true;
   }
   // the same strategy with the total cost formed by the caller's host callback (mas_hip_set_cost_exchange: torch.distributed / gloo)
   void run_line_search_host_exchange(int max_outer) {
@@ -405,18 +413,15 @@ class SolverImpl final : public SolverBase {
   // sum of all agents' costs in global block order + the decision of `mode`, on the stream
   void joint_sum_device(int mode) {
     const double* costs = cost; int n = d.N;
-#if !defined(MAS_HOST_EMULATION)
     if (comm_exchange) {
       int lo = 0, hi = 0; shard_range(comm_total, comm_exchange->n_ranks, comm_exchange->rank, &lo, &hi);
       be.d2d(comm_costs + lo, cost, sizeof(double) * d.N);
       comm_exchange->all_gather_shards(comm_costs, comm_total, 1, be.cur);
       costs = comm_costs; n = comm_total;
     }
-#endif
     be.launch_group("joint_sum", JointSumBody{costs, n, joint, mode}, 64);
   }
   void set_comm_exchange(void* comm, int n_total) override {
-#if !defined(MAS_HOST_EMULATION)
     comm_exchange = static_cast<Comm*>(comm);
     if (comm_exchange) {
       int lo = 0, hi = 0; shard_range(n_total, comm_exchange->n_ranks, comm_exchange->rank, &lo, &hi);
@@ -424,15 +429,11 @@ class SolverImpl final : public SolverBase {
       if (comm_total != n_total || !comm_costs) comm_costs = dalloc(static_cast<size_t>(n_total));
       comm_total = n_total;
     }
-#else
-    (void)comm; (void)n_total; throw std::logic_error("no RCCL in the host emulation");
-#endif
   }
   // publish step of the Nash strategies (update_initial_with_best for coupled costs, nash.hpp:66-71): every rank receives every
   // agent's trajectory and cost in the reference layout, [n_total][T+1][nx], [n_total][T][nu], [n_total].  The shard is written
   // straight to its displacement in the caller's buffers (layout conversion on the device) and travels as one collective per array.
   void all_gather_solution(void* comm_, int n_total, double* X_all, double* U_all, double* cost_all) override {
-#if !defined(MAS_HOST_EMULATION)
     const Comm* c = static_cast<const Comm*>(comm_);
     if (!c) throw std::invalid_argument("null communicator");
     int lo = 0, hi = 0; shard_range(n_total, c->n_ranks, c->rank, &lo, &hi);
@@ -442,9 +443,6 @@ class SolverImpl final : public SolverBase {
     if (U_all) { be.template launch_2d<4>("soa_to_aos", SoaToAosBody{d, NU, U, U_all + lo * pu, d.T}, d.N, d.T); c->all_gather_shards(U_all, n_total, pu, be.cur); }
     if (cost_all) { be.d2d(cost_all + lo, cost, sizeof(double) * d.N); c->all_gather_shards(cost_all, n_total, 1, be.cur); }
     be.sync();
-#else
-    (void)comm_; (void)n_total; (void)X_all; (void)U_all; (void)cost_all; throw std::logic_error("no RCCL in the host emulation");
-#endif
   }
 
   void run_centralized() override {                      // centralized.hpp:18-38, block-diagonal reading
@@ -1235,9 +1233,7 @@ class SolverImpl final : public SolverBase {
   bool al_enabled = true, al_rho_dirty = false;
   double *X_old = nullptr, *U_old = nullptr, *cost_old = nullptr, *U_cand = nullptr, *radii = nullptr;
   JointState *joint = nullptr, *host_joint = nullptr;     // Nash line search decided on the device; its pinned read-back copy
-#if !defined(MAS_HOST_EMULATION)
   Comm* comm_exchange = nullptr;                          // RCCL communicator of the sharded block list (owned by the caller)
-#endif
   double* comm_costs = nullptr; int comm_total = 0;       // [comm_total] every rank's costs in global block order
   int *slot_of[2] = {nullptr, nullptr}, *fused_error = nullptr;   // fused rounds: every agent's position in live_lists[k]; raised when a bounded LDS wait gave up
   int *live_lists[2] = {nullptr, nullptr}, *live_count0 = nullptr;   // agents still active, compacted by select (round r reads list r & 1, writes the other); count of round 0 (= N)

@@ -413,32 +413,12 @@ inline std::vector<int> device_plan() {
 // shards smaller than this stay on one device (a handle per device costs ~1 ms to set up)
 constexpr int kMinAgentsPerShard = 32;
 
-// total cost over the shards of one process when two of them share a device (RCCL refuses two ranks on one GPU): the host-callback
-// exchange of include/mas_hip.h -- every shard deposits its costs at its displacement, all meet at a barrier, each forms the sum in
-// global block order
-struct HostExchange {
-  std::vector<double> all; std::vector<int> lo; int parties = 0;
-  std::mutex m; std::condition_variable cv; int arrived = 0; long generation = 0;
-  void barrier() {
-    std::unique_lock<std::mutex> lk(m);
-    const long g = generation;
-    if (++arrived == parties) { arrived = 0; ++generation; cv.notify_all(); }
-    else cv.wait(lk, [&] { return generation != g; });
-  }
-  struct Party { HostExchange* ex; int rank; };
-  static int callback(void* ctx, const double* costs, int32_t n, double* total) {
-    auto* p = static_cast<Party*>(ctx);
-    std::copy(costs, costs + n, p->ex->all.begin() + p->ex->lo[p->rank]);
-    p->ex->barrier();
-    double s = 0.0; for (double v : p->ex->all) s += v;      // detail::compute_total_cost: c += cost, in block order
-    *total = s;
-    p->ex->barrier();                                         // nobody overwrites `all` before everybody has summed it
-    return 0;
-  }
-};
-
 // run `run(batch)` on the members of one homogeneous group, sharded over the device plan; `coupled`: the shards exchange the total
-// cost of all agents (line search) -- over RCCL inside the library when every shard has its own device, through HostExchange otherwise
+// cost of all agents (line search) through mas_hip_set_comm_cost_exchange -- over RCCL when every shard has its own device, over the
+// library's in-process loopback transport when two shards share one (RCCL refuses two ranks on a GPU; tests on a one-GPU box).
+// Nothing that can fail is left for after the first collective: phase 1 creates every handle, uploads and installs the
+// exchange on every shard, and only when ALL shards stand does phase 2 start the strategy; a shard that fails in phase 2 (a kernel
+// gave up, a device error) aborts every communicator of the group, so that no peer waits for it inside a collective.
 template <class Run>
 inline void run_sharded(MultiAgentProblem& problem, const std::vector<int>& members, const SolverParams& params, bool publish_initial,
                         std::vector<int>& iterations, bool coupled, Run&& run) {
@@ -456,31 +436,44 @@ inline void run_sharded(MultiAgentProblem& problem, const std::vector<int>& memb
   bool distinct = true;
   for (int i = 0; i < shards; ++i) for (int j = i + 1; j < shards; ++j) if (plan[i] == plan[j]) distinct = false;
   std::vector<mas_hip_comm*> comms(shards, nullptr);
-  HostExchange host; std::vector<HostExchange::Party> parties(shards);
+  struct CommGuard {
+    std::vector<mas_hip_comm*>& c;
+    ~CommGuard() { for (auto* p : c) if (p) mas_hip_comm_destroy(p); }
+  } guard{comms};
   if (coupled) {
-    if (distinct) { if (mas_hip_comm_create_all(shards, plan.data(), comms.data()) != MAS_HIP_OK) throw HipError(MAS_HIP_ERR_RUNTIME, std::string("mas_hip_comm_create_all: ") + mas_hip_comm_last_error()); }
-    else { host.all.assign(n_total, 0.0); host.lo.resize(shards); host.parties = shards; }
+    if (!distinct) mas_hip_comm_use_loopback(1);          // (communicators keep the transport they were made by)
+    const int rc = mas_hip_comm_create_all(shards, plan.data(), comms.data());
+    if (!distinct) mas_hip_comm_use_loopback(0);
+    if (rc != MAS_HIP_OK) throw HipError(MAS_HIP_ERR_RUNTIME, std::string("mas_hip_comm_create_all: ") + mas_hip_comm_last_error());
   }
+  using Uploaded = BatchedProblem;
+  std::vector<std::unique_ptr<Uploaded>> batches(shards);
   std::vector<std::exception_ptr> errors(shards);
-  std::vector<std::thread> threads;
-  for (int r = 0; r < shards; ++r) {
+  auto in_parallel = [&](auto&& body) {
+    std::vector<std::thread> threads;
+    for (int r = 0; r < shards; ++r) threads.emplace_back([&, r] { try { body(r); } catch (...) { errors[r] = std::current_exception(); } });
+    for (auto& t : threads) t.join();
+  };
+  // phase 1: everything that can fail before a collective
+  in_parallel([&](int r) {
     int lo = 0, hi = 0; mas_hip_shard_range(n_total, shards, r, &lo, &hi);
-    if (coupled && !distinct) { host.lo[r] = lo; parties[r] = {&host, r}; }
-    threads.emplace_back([&, r, lo, hi] {
-      try {
-        const std::vector<int> mine(members.begin() + lo, members.begin() + hi);
-        auto bp = upload(problem, mine, params, true, plan[r]);
-        if (coupled) {
-          if (distinct) bp.batch->check(mas_hip_set_comm_cost_exchange(bp.batch->get(), comms[r], n_total), "set_comm_cost_exchange");
-          else bp.batch->check(mas_hip_set_cost_exchange(bp.batch->get(), &HostExchange::callback, &parties[r]), "set_cost_exchange");
-        }
-        run(*bp.batch);
-        download_into(problem, bp, publish_initial, iterations);     // every shard writes its own OCPs and its own entries of `iterations`
-      } catch (...) { errors[r] = std::current_exception(); }
-    });
-  }
-  for (auto& t : threads) t.join();
-  for (auto* c : comms) if (c) mas_hip_comm_destroy(c);
+    const std::vector<int> mine(members.begin() + lo, members.begin() + hi);
+    batches[r] = std::make_unique<Uploaded>(upload(problem, mine, params, true, plan[r]));
+    if (coupled) batches[r]->batch->check(mas_hip_set_comm_cost_exchange(batches[r]->batch->get(), comms[r], n_total), "set_comm_cost_exchange");
+  });
+  for (auto& e : errors) if (e) std::rethrow_exception(e);        // no collective has started: nobody waits for anybody
+  // phase 2: the strategy; a failing shard releases its peers
+  std::once_flag abort_once;
+  in_parallel([&](int r) {
+    try {
+      run(*batches[r]->batch);
+      download_into(problem, *batches[r], publish_initial, iterations);     // every shard writes its own OCPs and its own entries of `iterations`
+    } catch (...) {
+      std::call_once(abort_once, [&] { for (auto* c : comms) if (c) mas_hip_comm_abort(c); });
+      throw;
+    }
+  });
+  batches.clear();                                                  // the handles go before their communicators (CommGuard)
   for (auto& e : errors) if (e) std::rethrow_exception(e);
 }
 

@@ -833,6 +833,9 @@ static double collect_total(mas_ocp** ocps, int n) {   /* collect_solution, nash
  * nothing (ilqr.hpp:58-273), the product reports it as an extension and the tests check it against this */
 static int* g_exit_out = NULL;
 void mas_oracle_set_exit_buffer(int* buf) { g_exit_out = buf; }
+/* the trust radii the trust-region strategy ends with (nash.hpp:184,231,241), handed to mas_run_trust_region by mas_oracle_solve_batch */
+static double* g_radii_out = NULL;
+void mas_oracle_set_radii_buffer(double* buf) { g_radii_out = buf; }
 static void report_exits(const mas_ilqr* sv, int n) { if (g_exit_out) for (int i = 0; i < n; ++i) g_exit_out[i] = sv[i].exit_reason; }
 
 static double g_al_params[4] = {10.0, 5.0, 1e-4, 1e-6};
@@ -1397,7 +1400,7 @@ double mas_oracle_solve_batch(int model_id, const double* params, int N, int T, 
   double total = NAN;
   switch (strategy) {
     case 0: total = mas_run_sequential(ocps, N, max_outer, max_iterations, tolerance, max_ms, stats, iters); break;
-    case 1: total = mas_run_trust_region(ocps, N, max_outer, max_iterations, tolerance, max_ms, stats, NULL, iters); break;
+    case 1: total = mas_run_trust_region(ocps, N, max_outer, max_iterations, tolerance, max_ms, stats, g_radii_out, iters); break;
     case 2: total = mas_run_line_search(ocps, N, max_outer, max_iterations, tolerance, max_ms, stats, iters); break;
     case 3: { mas_strategy_stats st; memset(&st, 0, sizeof(st));
               total = mas_run_centralized_dense(ocps, N, max_iterations, tolerance, max_ms, &st);

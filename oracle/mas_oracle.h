@@ -238,6 +238,7 @@ int mas_oracle_max_threads(void);
 /* AL parameters given to every solver the strategy drivers create (defaults 10, 5, 1e-4, 1e-6) */
 /* buf [N] or NULL: receives enum mas_exit_reason of every agent's last solve (Nash strategies) */
 void mas_oracle_set_exit_buffer(int* buf);
+void mas_oracle_set_radii_buffer(double* buf);   /* optional [N]: final trust radii of the trust-region strategy (mas_oracle_solve_batch) */
 void mas_oracle_set_al_params(double penalty, double penalty_increase, double constraint_tolerance, double inequality_activation_tolerance);
 /* 0 = platform libm (faithful to a glibc-linked reference binary), 1 = include/mas_dettrig.h */
 void mas_oracle_set_trig_mode(int mode);

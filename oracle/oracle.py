@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         _lib.mas_oracle_get_trig_mode.restype = C.c_int
         _lib.mas_oracle_set_al_params.argtypes = [C.c_double] * 4
         _lib.mas_oracle_set_exit_buffer.argtypes = [i]
+        _lib.mas_oracle_set_radii_buffer.argtypes = [d]
         for name in ("mas_ref_case_initialize", "mas_ref_case_update_initial", "mas_ref_case_global",
                      "mas_ref_case_fd_gradient"):
             getattr(_lib, name).argtypes = [d]
@@ -124,7 +125,7 @@ def solve_batch(model_id, x0, U0, T, dt, strategy="sequential", max_outer=10, ma
                 tolerance=1e-5, max_ms=math.inf, params=None, threads=0):
     """Run a strategy over N agents.  x0 [N,nx]; U0 [N,T,nu] (reference column layout: one
     control column per step) or None for zeros.  Returns dict(X [N,T+1,nx], U [N,T,nu], cost [N],
-    iters [N], total_cost, stats)."""
+    iters [N], total_cost, stats) and, for the trust-region strategy, radii [N]."""
     nx, nu, _ = model_dims(model_id)
     x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, nx)
     N = x0.shape[0]
@@ -138,13 +139,17 @@ def solve_batch(model_id, x0, U0, T, dt, strategy="sequential", max_outer=10, ma
         par = np.concatenate([par, np.zeros(16 - par.size)])
     status = np.full(N, -1, dtype=np.int32)        # exit reason of each agent's last solve; stays -1 for the centralised strategies
     lib().mas_oracle_set_exit_buffer(status.ctypes.data_as(C.POINTER(C.c_int)))
+    radii = np.ones(N) if strategy == "trustregion" else None   # final trust radii (nash.hpp:184,231,241)
+    lib().mas_oracle_set_radii_buffer(_p(radii))
     try:
         total = lib().mas_oracle_solve_batch(model_id, _p(par), N, T, float(dt), _p(x0), _p(U), _p(X), _p(cost),
                                              iters.ctypes.data_as(C.POINTER(C.c_int)), STRATEGY[strategy], max_outer,
                                              max_iterations, float(tolerance), float(max_ms), threads, C.byref(st))
     finally:
         lib().mas_oracle_set_exit_buffer(None)
-    return dict(X=X, U=U, cost=cost, iters=iters, status=status, total_cost=total,
+        lib().mas_oracle_set_radii_buffer(None)
+    extra = {} if radii is None else {"radii": radii}
+    return dict(X=X, U=U, cost=cost, iters=iters, status=status, total_cost=total, **extra,
                 stats=dict(total_iterations=st.total_iterations, converged_solves=st.converged_solves,
                            reg_events=st.reg_events, trials=st.trials, alpha_hist=list(st.alpha_hist)))
 

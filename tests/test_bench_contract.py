@@ -17,8 +17,20 @@ def _check_line(j, n_gpus):
     assert j["n_gpus"] == n_gpus and j["scaling"] == "weak" and j["dtype"] == "f64" and j["vs_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the contract's figure (algorithmic bytes / kernel time against the HBM peak) ...
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
+    # ... and what actually binds the kernel (round 4): the fused kernel keeps its tiles in LDS and follows the recursion's FP64 chain
+    assert r["bound"] == ("fp64_issue" if r["kernel"] == "mas_linearise_riccati_kernel" else "hbm") and "frac_is" in r
+    f = r["fp64"]
+    assert f["unit"] == "TFLOP/s" and f["peak"] == 78.6 and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-12 and 0.0 < f["frac"] < 1.0
+    assert "issue_fill" in f and "issue_fill_source" in f           # a number only with SQ counters collected from these very sources, else null + reason
+    assert (f["issue_fill"] is None) or (0.0 < f["issue_fill"] < 1.0)
+    ls = r["line_search"]
+    assert ls["bound"] == "fp64_issue" and 0.0 < ls["fp64"]["frac"] < 1.0
+    rf = r["round_fill"]
+    assert ("value" in rf) and ((rf["value"] is None and "reason" in rf) or (0.0 < rf["value"] < 1.0))
+    assert "hbm_measured" in r and ((r["hbm_measured"] is None) == (r["traffic"] is None))
     assert j["value"] > 0 and j["ms_per_step"] > 0
 
 
@@ -42,6 +54,7 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     # backward bytes of SURVEY 8(d)), and the sweep as a kernel of its own is measured in the same run with the five-kernel round
     r = j["roofline"]
     assert r["kernel"] == "mas_linearise_riccati_kernel" and r["algorithmic_bytes_per_agent"] == 51392 + 54432
+    assert r["fp64"]["flops_per_agent_launch"] == 100 * (12 * 150 + 118 * 25) + 100 * 802      # 4.8e5 (linearisation) + ~700-800 per backward step
     u = j["unfused_round"]
     assert u["ms_per_step"] > 0 and u["speedup_of_the_fused_round"] > 0.9 and r_has_both_fracs(u["roofline_sweep"])
     assert "traffic" in r and "traffic_source" in r          # a number only with counters collected from these very sources, else null + reason

@@ -34,6 +34,8 @@ def _same(e, o, total_exact=True):
     assert e["stats"]["reg_events"] == o["stats"]["reg_events"]
     if (o["status"] >= 0).all():                    # the oracle reports exit reasons for the Nash strategies
         assert (e["status"] & 3).tolist() == o["status"].tolist()
+    if "radii" in o:                                # trust-region strategy: the radii every agent ends with (nash.hpp:231,241)
+        assert "radii" in e and np.array_equal(e["radii"], o["radii"])
     if total_exact:
         assert e["total_cost"] == o["total_cost"]
     else:
@@ -80,6 +82,22 @@ def test_lqr_identity(gpu_lib, oracle):
     _same(e, o)
 
 
+@pytest.mark.parametrize("strategy,outer", [("sequential", 10), ("trustregion", 3), ("linesearch", 2), ("centralized", 1)])
+def test_lqr_identity_against_the_oracle_in_libm_mode(gpu_lib, oracle, strategy, outer):
+    """The one parity statement that does NOT pass through the sin / cos / tan header the product and the oracle's `det` mode share
+    (include/mas_dettrig.h): the identity LQR has no trigonometry, so the oracle in its glibc-faithful `libm` mode -- what a
+    glibc-linked reference binary computes -- must be met bit for bit too (perturbed agents, so that they differ)."""
+    rng = np.random.default_rng(5)
+    x0 = oracle.lqr_x0(70) + 0.2 * rng.standard_normal((70, 4))
+    oracle.set_trig_mode("libm")
+    try:
+        o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, strategy=strategy, max_outer=outer)
+    finally:
+        oracle.set_trig_mode("det")
+    e = run_batch(gpu_lib, oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, strategy, max_outer=outer)
+    _same(e, o, total_exact=(strategy != "centralized"))
+
+
 @pytest.mark.parametrize("T", [50, 60])
 def test_pendulum(gpu_lib, oracle, T):
     x0, U0 = oracle.pendulum_problem(T, 0.05)
@@ -99,8 +117,8 @@ def test_bicycle6_trust_region(gpu_lib, oracle):
     x0 = oracle.bicycle6_x0(4)
     e = run_batch(gpu_lib, oracle.MODEL_BICYCLE6, x0, None, 200, 0.25, "trustregion")
     o = oracle.solve_batch(oracle.MODEL_BICYCLE6, x0, None, 200, 0.25, strategy="trustregion")
-    _same(e, o)
-    assert np.array_equal(e["radii"], np.array(e["radii"]))   # radii returned
+    _same(e, o)                                    # (includes the trust radii)
+    assert set(np.unique(np.log(o["radii"]) / np.log(1.5)).round(6)) != {0.0}      # and they moved: accepted steps grow the radius by 1.5, reverted ones halve it
 
 
 def test_edge_cases_ragged_and_tiny(gpu_lib, oracle):
@@ -426,6 +444,19 @@ def test_division_by_an_invariant_divisor_is_the_ieee_quotient():
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     r = subprocess.run([exe, "10"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_sin_cos_tan_on_the_device_are_the_oracles_bits_and_within_an_ulp_of_glibc():
+    """include/mas_dettrig.h evaluated on the DEVICE: (1) the same bits as the host evaluation of the same header -- what the CPU
+    oracle's `det` mode computes, i.e. what every trigonometric parity test silently relies on -- and (2) <= 1 ulp (sin, cos) /
+    <= 3 ulp (tan) from glibc, densely over the argument ranges the workloads reach (steering angles, headings of a lap, pendulum
+    angles) and +-1e5.  tests/hip/dettrig_check.hip; tests/test_dettrig.py holds (2) for the CPU build only."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "hip", "build", "dettrig_check")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches between device and host evaluation" in r.stdout and "within 1 / 1 / 3" in r.stdout, (r.stdout, r.stderr[-500:])
 
 
 @pytest.mark.parametrize("model,T,dt,strategy,outer", [("MODEL_SINGLE_TRACK", 60, 0.5, "sequential", 4), ("MODEL_SINGLE_TRACK", 40, 0.5, "trustregion", 3),

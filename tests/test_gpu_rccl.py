@@ -104,3 +104,75 @@ def test_two_handles_two_host_threads_one_device(product_lib, oracle):
     for key in ("cost", "X", "U", "iters", "status", "radii"):
         assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key]), key
     assert sum(p["stats"]["agent_iterations"] for p in parts) == whole["stats"]["agent_iterations"]
+
+
+def _torch_alloc(shape):
+    import torch
+    t = torch.full(shape, float("nan"), dtype=torch.float64, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    return t, t.data_ptr()
+
+
+@pytest.mark.parametrize("n_ranks,N,strategy", [(3, 10, "linesearch"), (3, 9, "linesearch"), (2, 130, "linesearch"), (4, 70, "trustregion")])
+def test_several_ranks_on_one_gpu_over_the_loopback_transport(product_lib, oracle, n_ranks, N, strategy):
+    """The library's multi-rank logic with more than one rank ON THE DEVICE: n shards of one problem on the box's single GPU, each with its
+    own handle, stream and host thread, their communicators made by mas_hip_comm_create_all over the in-process loopback transport
+    (RCCL refuses several ranks per device; csrc/mas_rccl.hpp) -- device-side layout conversion straight to the shard's displacement,
+    even and uneven shards, the line search's total over all ranks' costs summed by one wavefront in global block order.  Every
+    shard bit-equal to one handle holding all agents; the all-gathered Solution complete on every rank; the total the very bits of
+    the one handle's.  (tests/test_loopback_ranks.py: the same through the host emulation, to 8 ranks.)"""
+    from test_loopback_ranks import check_against_one_handle
+    model = oracle.MODEL_SINGLE_TRACK
+    check_against_one_handle(product_lib, oracle, n_ranks, N, model, 30, 0.5, strategy, 3, alloc=_torch_alloc, to_numpy=lambda t: t.cpu().numpy())
+
+
+def test_a_failing_rank_releases_its_peers_on_the_device(product_lib, oracle):
+    from test_loopback_ranks import run_ranks
+    x0 = oracle.single_track_x0(9)
+    out, errors, hung = run_ranks(product_lib, 3, oracle.MODEL_SINGLE_TRACK, x0, 10, 0.5, "linesearch", 2, _torch_alloc, lambda t: t.cpu().numpy(), fail_rank=2)
+    assert not hung and isinstance(errors[2], RuntimeError)
+    assert all(errors[r] is not None and out[r] is None for r in (0, 1)), errors
+
+
+def test_two_ranks_on_two_gpus_over_rccl(product_lib, oracle):
+    """librccl itself with MORE than one rank: two GPUs, uneven shards (grouped in-place broadcasts) and the line-search exchange,
+    bit-equal to one handle.  Skipped on a one-GPU box -- which every box of this pool is: the collectives have run over librccl with
+    one rank only; everything above the table of function pointers is pinned by the loopback tests."""
+    if product_lib.mas_hip_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch
+    from multi_agent_solver_amd.batch import BatchSolver, Comm
+    N, T = 11, 20
+    x0 = oracle.single_track_x0(N)
+    whole = run_batch(product_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "linesearch", max_outer=3)
+    comms = Comm.create_all([0, 1], lib=product_lib)
+    out, errors = [None, None], [None, None]
+
+    def worker(r):
+        try:
+            lo, hi = comms[r].shard_range(N)
+            with BatchSolver(oracle.MODEL_SINGLE_TRACK, hi - lo, T, 0.5, lib=product_lib, device=r) as s:
+                s.set_params({"max_iterations": 100, "tolerance": 1e-5, "max_ms": math.inf})
+                s.set_initial_states(x0[lo:hi]); s.set_controls(None); s.initialize_problem()
+                s.set_comm_cost_exchange(comms[r], N)
+                s.run_line_search(3)
+                sol = s.solution()
+                dev = torch.device("cuda", r)
+                X = torch.full((N, T + 1, 4), float("nan"), dtype=torch.float64, device=dev)
+                torch.cuda.synchronize(dev)
+                s.all_gather_solution_device(comms[r], N, X.data_ptr(), 0, 0)
+                out[r] = (lo, hi, sol, X.cpu().numpy())
+        except Exception as e:      # noqa: BLE001
+            errors[r] = e
+            comms[r].abort()
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads) and errors == [None, None], errors
+    for lo, hi, sol, X in out:
+        assert np.array_equal(sol["cost"], whole["cost"][lo:hi]) and sol["total_cost"] == whole["total_cost"] and np.array_equal(X, whole["X"])
+    for c in comms:
+        c.close()

@@ -19,6 +19,8 @@ def _same(e, o, total_exact=True):
     assert np.array_equal(e["U"], o["U"])
     assert e["iters"].tolist() == o["iters"].tolist()
     assert e["stats"]["reg_events"] == o["stats"]["reg_events"]
+    if "radii" in o:                                # trust-region strategy: the radii every agent ends with (nash.hpp:231,241)
+        assert "radii" in e and np.array_equal(e["radii"], o["radii"])
     if total_exact:
         assert e["total_cost"] == o["total_cost"]
     else:
@@ -61,6 +63,21 @@ def test_lqr_identity_sequential(hostcheck_lib, oracle):
     o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, strategy="sequential")
     _same(e, o)
     assert e["iters"].tolist() == [109, 109, 109]      # first solve hits max_iterations=100, then 9 x 1
+
+
+@pytest.mark.parametrize("strategy,outer", [("sequential", 10), ("trustregion", 3), ("linesearch", 2)])
+def test_lqr_identity_against_the_oracle_in_libm_mode(hostcheck_lib, oracle, strategy, outer):
+    """no trigonometry in this workload: the product's lane arithmetic must meet the oracle's glibc-faithful mode bit for bit too --
+    the parity statement that does not pass through include/mas_dettrig.h (the GPU tier repeats it on the device)"""
+    rng = np.random.default_rng(5)
+    x0 = oracle.lqr_x0(9) + 0.2 * rng.standard_normal((9, 4))
+    oracle.set_trig_mode("libm")
+    try:
+        o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, strategy=strategy, max_outer=outer)
+    finally:
+        oracle.set_trig_mode("det")
+    e = run_batch(hostcheck_lib, oracle.MODEL_LQR_IDENTITY, x0, None, 50, 0.1, strategy, max_outer=outer)
+    _same(e, o)
 
 
 @pytest.mark.parametrize("T", [50, 60])

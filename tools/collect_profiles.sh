@@ -7,7 +7,7 @@
 #   4. tools/summarise_profiles.py -> profiles/<tag>_*_W.{json,csv}
 # Counter passes never combine --pmc with a sys/hip/hsa trace (gpurun refuses that); the program after `--` is python3 itself.
 set -e
-W=${1:-c3}; TAG=${2:-r3}
+W=${1:-c3}; TAG=${2:-r4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
 rm -rf "$OUT"; mkdir -p "$OUT"

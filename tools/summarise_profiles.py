@@ -19,7 +19,7 @@ os.makedirs(PROF, exist_ok=True)
 
 KERNELS = (("linearise_riccati", ("mas_linearise_riccati_kernel",)), ("sweep", ("mas_sweep_kernel", "SweepBody")), ("central_backward", ()),
            ("backward", ("mas_backward_tile_kernel", "mas_backward_row_kernel", "BackwardBody")), ("forward", ("ForwardBody",)), ("select", ("SelectBody",)),
-           ("commit", ("CommitBody", "CommitSlotBody")), ("trust_reroll", ("TrustRerollBody",)), ("trust_norm", ("TrustNormBody",)), ("trust_copy", ("TrustCopyBody",)),
+           ("commit", ("CommitBody", "CommitSlotBody")), ("trust_epilogue", ("mas_trust_epilogue_kernel",)), ("trust_reroll", ("TrustRerollBody",)), ("trust_norm", ("TrustNormBody",)), ("trust_copy", ("TrustCopyBody",)),
            ("trust_region", ("TrustRegion",)), ("rollout_cost", ("RolloutCostBody",)))
 
 
