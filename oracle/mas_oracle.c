@@ -1050,6 +1050,8 @@ double mas_run_centralized_dense(mas_ocp** ocps, int n, int max_iterations, doub
   return total;
 }
 
+#include "mas_oracle_dense_impl.h"   /* the same solve with exact re-use + OpenMP: mas_run_centralized_dense_structured */
+
 /* sum over blocks of the stacked objective, in the stacked problem's order:
  * for each t the block costs are added in block order, then the stage sums in t order
  * (global_stage inside compute_trajectory_cost). */
@@ -1411,6 +1413,10 @@ double mas_oracle_solve_batch(int model_id, const double* params, int N, int T, 
               if (iters) for (int i = 0; i < N; ++i) iters[i] = (int)st.total_iterations;
               if (stats) *stats = st; } break;
     case 5: total = mas_run_sequential(ocps, N, 1, max_iterations, tolerance, max_ms, stats, iters); break;
+    case 6: { mas_strategy_stats st; memset(&st, 0, sizeof(st));
+              total = mas_run_centralized_dense_structured(ocps, N, max_iterations, tolerance, max_ms, &st);
+              if (iters) for (int i = 0; i < N; ++i) iters[i] = (int)st.total_iterations;
+              if (stats) *stats = st; } break;
     default: break;
   }
   for (int i = 0; i < N; ++i) {

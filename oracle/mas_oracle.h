@@ -197,6 +197,10 @@ double mas_run_line_search(mas_ocp** ocps, int n, int max_outer, int max_iterati
  * O(N^3) work with FD -- small N only. */
 double mas_run_centralized_dense(mas_ocp** ocps, int n, int max_iterations, double tolerance, double max_ms,
                                  mas_strategy_stats* stats);
+/* The same dense solve, the same numbers, with exact re-use (prefix sums of the summed cost's chain, the block structure of A and B)
+ * and OpenMP over independent output entries, so that it reaches config 2's 256 agents: mas_oracle_dense_impl.h. */
+double mas_run_centralized_dense_structured(mas_ocp** ocps, int n, int max_iterations, double tolerance, double max_ms,
+                                            mas_strategy_stats* stats);
 /* Same algorithm under the exact-block-diagonal reading of the stacked problem
  * (SURVEY.md section 7): per-agent blocks, but alpha / acceptance / termination
  * (ilqr.hpp:206-228,269) and the regularisation ladder (ilqr.hpp:172-182) are
@@ -226,7 +230,7 @@ void     mas_model_default_params(int model_id, int T, double* params);
 
 /* Batched convenience driver used by tests / bench (python ctypes):
  * strategy: 0 sequential, 1 trustregion, 2 linesearch, 3 centralized dense, 4 centralized blocked,
- *           5 = single solve per agent (no strategy layer; max_outer ignored)
+ *           5 = single solve per agent (no strategy layer; max_outer ignored), 6 centralized dense with exact re-use (structured)
  * x0 [N*nx], U [N*nu*T] in/out (reference layout per agent), X [N*nx*(T+1)] out, cost [N] out,
  * iters [N] out (total iLQR iterations per agent; centralized: same value for all), stats optional.
  * Returns total cost (Solution.total_cost).  threads <= 0 => omp default. */

@@ -24,7 +24,7 @@ MODEL_BICYCLE6 = 5
 MODEL_SINGLE_TRACK_LIMITED = 6
 
 STRATEGY = {"sequential": 0, "trustregion": 1, "linesearch": 2, "centralized_dense": 3,
-            "centralized": 4, "single": 5}
+            "centralized": 4, "single": 5, "centralized_dense_structured": 6}
 
 
 class StrategyStats(C.Structure):
@@ -36,7 +36,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("mas_oracle.c", "mas_oracle.h", "ref_unit_cases.c", "Makefile", "../include/mas_dettrig.h")):
+            for f in ("mas_oracle.c", "mas_oracle_dense_impl.h", "mas_oracle.h", "ref_unit_cases.c", "Makefile", "../include/mas_dettrig.h")):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
