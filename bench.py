@@ -161,6 +161,38 @@ def measure(w, n_local, first, n_total, device, steps, warmup, sync, barrier, af
     return elapsed, st, kt, sol
 
 
+def literal_stacked_solve_block(w, device, block_diagonal_total):
+    """BASELINE configs[1] under the reference's LITERAL algorithm -- one iLQR on the stacked OCP, every cost derivative a finite difference of the
+    SUMMED cost (centralized.hpp:18-38, multi_agent_problem.hpp:94-122) -- on the device (mas_hip_run_centralized_dense, chip-wide launches:
+    csrc/mas_dense_chip.hpp), timed, and held against the CPU oracle's structured restatement of the same solve through the committed vectors
+    tests/golden/centralized_dense_large.json (tools/make_dense_goldens.py: ten minutes of eight cores at 256 agents)."""
+    import hashlib
+    import numpy as np
+    s = make_solver(w, w["agents"], 0, w["agents"], device)
+    times = []
+    for _ in range(2):                                   # (the first run allocates the stacked problem's 3.5 GB)
+        s.restore_initial(); s.reset_stats()
+        t0 = time.perf_counter(); s.run("centralized_dense", 1); times.append(time.perf_counter() - t0)
+    st, sol, total = s.stats(), s.solution(), s.total_cost()
+    s.set_profiling(True); s.restore_initial(); s.run("centralized_dense", 1); kt = s.kernel_times(); s.close()
+    out = {"what": "the reference's literal centralised algorithm at this size: 4 (N nx)^2 evaluations of the N-agent cost per time step, dense n = N nx / m = N nu "
+                   "Riccati recursion (LLT of 512 x 512 with the x10 ladder, its inverse, K, V) -- the same numbers by exact re-use only (DESIGN.md section 4)",
+           "agents": w["agents"], "seconds_per_solve": times[1], "first_solve_seconds": times[0], "iterations": int(st["agent_iterations"] // w["agents"]),
+           "value": st["agent_iterations"] / times[1], "unit": "agent-iterations/s", "total_cost": total,
+           "block_diagonal_reading_total_cost": block_diagonal_total,
+           "block_diagonal_vs_literal_total_rel": abs(block_diagonal_total - total) / abs(total),
+           "kernels_ms": {n: round(k["total_ms"], 2) for n, k in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}
+    path = os.path.join(ROOT, "tests", "golden", "centralized_dense_large.json")
+    g = json.load(open(path))["cases"].get(str(w["agents"])) if os.path.exists(path) else None
+    if g is not None and w["T"] == g["horizon"]:
+        same = (float(total).hex() == g["total_cost"] and [float(v).hex() for v in sol["cost"]] == g["cost"] and
+                hashlib.sha256(np.ascontiguousarray(sol["X"]).tobytes()).hexdigest() == g["sha256_X"] and
+                hashlib.sha256(np.ascontiguousarray(sol["U"]).tobytes()).hexdigest() == g["sha256_U"] and out["iterations"] == g["iterations"])
+        out["vs_oracle_structured_restatement"] = "exact" if same else "DIFFERENT"
+        out["oracle_seconds_for_the_same_solve"] = g["oracle_seconds"]
+    return out
+
+
 def oracle_run(w, x0, trig, threads=0):
     from oracle import oracle as O
     O.set_trig_mode(trig)
@@ -521,6 +553,8 @@ def main():
                 "roofline_sweep": roofline_of(uk, w, args.workload, "sweep")}
         out["parity"] = parity_block(w, sol, n_total) if (world == 1 and not args.no_parity) else None
         out["cpu_baseline"] = cpu_baseline(w, n_total) if (world == 1 and not args.no_cpu_baseline) else None
+        if world == 1 and not args.no_also and args.workload == "c2":
+            out["literal_stacked_solve"] = literal_stacked_solve_block(w, device, float(sol["total_cost"]))
         if world == 1 and not args.no_also and args.workload == "c3":
             w2 = dict(WORKLOADS["c2"])
             el2, st2, kt2, sol2 = measure(w2, w2["agents"], 0, w2["agents"], device, max(3, args.steps), 1, sync, barrier)
@@ -528,6 +562,7 @@ def main():
                                    "ms_per_step": 1e3 * el2 / max(3, args.steps), "roofline": roofline_of(kt2, w2, "c2", "sweep"),
                                    "kernels_avg_us": {n: round(1e3 * k["total_ms"] / max(1, k["launches"]), 2) for n, k in kt2.items() if "_inkernel" not in n},
                                    "parity": None if args.no_parity else parity_block(w2, sol2, w2["agents"])}
+            out["also_config2"]["literal_stacked_solve"] = literal_stacked_solve_block(w2, device, float(sol2["total_cost"]))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

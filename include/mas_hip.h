@@ -166,9 +166,13 @@ int mas_hip_run_line_search(mas_hip_solver*, int max_outer);
 int mas_hip_run_centralized(mas_hip_solver*);
 /* CentralizedStrategy::operator() in the reference's LITERAL reading: one iLQR on the stacked OCP of build_global_ocp
  * (multi_agent_problem.hpp:52-127) -- finite differences of the SUMMED cost, dense stacked Hessians and gains, one shared
- * alpha / termination / regularisation by construction.  4 (N nx)^2 evaluations of the N-agent cost per time step: limited to
- * 64 agents (MAS_HIP_ERR_INVALID beyond), one workgroup, a correctness path (single-track, H = 100: 1 s at 16 agents, 7 s at 32,
- * 56 s at 64).  Per-agent costs are the agents' own objectives of
+ * alpha / termination / regularisation by construction.  4 (N nx)^2 evaluations of the N-agent cost per time step and a dense
+ * (N nx) x (N nx) Riccati recursion; computed as chip-wide launches with exact re-use only (csrc/mas_dense_chip.hpp: the prefix of the
+ * summed cost's own chain of additions, the exact zeros of the stacked A and B) up to 256 agents and 1024 stacked controls
+ * (MAS_HIP_ERR_INVALID beyond): single-track, H = 100: 0.1 s at 16 agents, 0.4 s at 64, 6 s at BASELINE config 2's 256.  Bit-equal to
+ * the CPU oracle's restatement.  mas_hip_set_option("dense_chip", 0) selects the one-workgroup form of rounds 2-3 (<= 64 agents, 56 s
+ * there).  Precondition of the re-use: finite value function (a diverged solve may differ in WHICH non-finite values it holds).
+ * Per-agent costs are the agents' own objectives of
  * the stacked solution and mas_hip_total_cost the stacked best_cost (centralized.hpp:26-35); iterations are the stacked solve's. */
 int mas_hip_run_centralized_dense(mas_hip_solver*);
 

@@ -258,7 +258,7 @@ class BatchSolver:
         self._check(self._lib.mas_hip_run_centralized(self._h))
 
     def run_centralized_dense(self):
-        """the reference's literal stacked solve (FD of the summed cost), N <= 64 (one workgroup: seconds beyond 16 agents)"""
+        """the reference's literal stacked solve (FD of the summed cost, dense Riccati recursion), N <= 256: chip-wide launches (csrc/mas_dense_chip.hpp)"""
         self._check(self._lib.mas_hip_run_centralized_dense(self._h))
 
     def run(self, strategy: str, max_outer: int = 10):

@@ -25,6 +25,7 @@
 #if !defined(MAS_HOST_EMULATION)
 #include "mas_kernels_hip.hpp"
 #include "mas_fused_hip.hpp"
+#include "mas_dense_chip.hpp"
 #endif
 
 namespace mas {
@@ -103,6 +104,7 @@ class SolverBase {
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
+    bool dense_chip = true;                 // the literal stacked solve as chip-wide launches (mas_dense_chip.hpp); false: one workgroup (mas_dense.hpp, <= 64 agents)
     int central_combine = 1, central_wpb = kCentralWavesPerBlock, central_peek = 1;
     bool set(const std::string& key, long long v) {
       if (key == "fused") fused = v != 0;
@@ -116,6 +118,7 @@ class SolverBase {
       else if (key == "central_pipeline") central_pipeline = v != 0;
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
+      else if (key == "dense_chip") dense_chip = v != 0;
       else if (key == "central_combine") central_combine = static_cast<int>(v);
       else if (key == "central_peek") central_peek = static_cast<int>(v);
       else if (key == "central_wpb") { if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) central_wpb = static_cast<int>(v); else return false; }
@@ -125,7 +128,7 @@ class SolverBase {
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
       static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
-                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek"};
+                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
         for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
@@ -216,6 +219,7 @@ class SolverImpl final : public SolverBase {
     if (round_events_made) for (auto& e : round_ev) be.drop_event(e);
     for (void* p : allocations) be.free(p);
     be.free_pinned(host_counters); be.free_pinned(host_central); if (host_joint) be.free_pinned(host_joint);
+    free_chip_word();
     be.destroy();
   }
 
@@ -543,6 +547,9 @@ class SolverImpl final : public SolverBase {
   void run_centralized_dense() override {
     Timer tm(*this);
     require(have_x0, "initial states not set");
+#if !defined(MAS_HOST_EMULATION)
+    if (switches.dense_chip) { run_centralized_dense_chip(); return; }
+#endif
     if (d.N > kDenseMaxAgents) throw std::invalid_argument("the literal stacked solve is limited to " + std::to_string(kDenseMaxAgents) +
                                                           " agents (4 (N nx)^2 evaluations of the N-agent cost per time step); use run_centralized");
     be.zero(U, sizeof(double) * d.T * NU * d.Np);       // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109)
@@ -563,6 +570,124 @@ class SolverImpl final : public SolverBase {
     controls_zero = false;
     initialized = false; rollout_consistent = false;     // cost[] now holds per-agent objectives of the stacked solution, merit[] is stale
   }
+
+#if !defined(MAS_HOST_EMULATION)
+  // The same literal solve as a sequence of chip-wide launches (mas_dense_chip.hpp): ~17 launches per time step of the backward pass,
+  // every decision (rung of the ladder, step size, termination) taken on the device; the host reads one pinned word per iteration.
+  void run_centralized_dense_chip() {
+    const int N = d.N, T = d.T, n = N * NX, m = N * NU;
+    if (N > kDenseChipMaxAgents || m > kDenseChipMaxM)
+      throw std::invalid_argument("the literal stacked solve is limited to " + std::to_string(kDenseChipMaxAgents) + " agents and " + std::to_string(kDenseChipMaxM) + " stacked controls");
+    using TB = DenseTables<NX, NU>;
+    const size_t n2 = static_cast<size_t>(n) * n, m2 = static_cast<size_t>(m) * m, mn = static_cast<size_t>(m) * n;
+    const size_t nXg = static_cast<size_t>(T + 1) * n, nUg = static_cast<size_t>(T) * m;
+    if (!chip_ready) {
+      DenseChipWs& w = chip;
+      w.S = static_cast<DenseChipState*>(raw_alloc(sizeof(DenseChipState)));
+      w.Xg = dalloc(nXg); w.Ug = dalloc(nUg); w.Xt = dalloc(kNumAlphas * nXg); w.Ut = dalloc(kNumAlphas * nUg);
+      w.Ab = dalloc(static_cast<size_t>(N) * NX * NX); w.Bb = dalloc(static_cast<size_t>(N) * NX * NU);
+      w.c = dalloc(N); w.pre = dalloc(N + 1); w.cx5 = dalloc(static_cast<size_t>(N) * NX * 2); w.cx6 = dalloc(static_cast<size_t>(N) * NX * 2);
+      w.cu5 = dalloc(static_cast<size_t>(N) * NU * 2); w.cu6 = dalloc(static_cast<size_t>(N) * NU * 2);
+      w.lx = dalloc(n); w.lu = dalloc(m); w.lxx = dalloc(n2); w.luu = dalloc(m2); w.lux = dalloc(mn);
+      w.k = dalloc(nUg); w.K = dalloc(static_cast<size_t>(T) * mn);
+      w.V = dalloc(n2); w.vx = dalloc(n); w.qx = dalloc(n); w.qu = dalloc(m); w.qxx = dalloc(n2); w.qux = dalloc(mn); w.quu = dalloc(m2);
+      w.Rr = dalloc(kDenseChipRungs * m2); w.Lt = dalloc(kDenseChipRungs * m2); w.inv = dalloc(m2);
+      w.tmp_xx = dalloc(n2); w.tmp_ux = dalloc(mn); w.V3 = dalloc(n2); w.KtQuu = dalloc(mn); w.gs = dalloc(static_cast<size_t>(kNumAlphas) * (T + 1));
+      chip_bounds = dalloc(2 * NU);
+      w.host_word = static_cast<long long*>(be.alloc_pinned(sizeof(long long)));
+      hipDeviceProp_t prop;
+      MAS_HIP_CHECK(hipGetDeviceProperties(&prop, be.device));
+      chip_cus = prop.multiProcessorCount;
+      chip_ready = true;
+    }
+    DenseChipWs w = chip;
+    { double hb[2 * NU]; for (int i = 0; i < NU; ++i) { hb[i] = lb[i]; hb[NU + i] = ub[i]; } be.h2d(chip_bounds, hb, sizeof(hb)); }
+    be.zero(U, sizeof(double) * T * NU * d.Np);          // (overwritten by the hand-back; the stacked OCP starts from zero controls)
+    auto grid_for = [&](long long items, int block) { return dim3(static_cast<unsigned>(std::max<long long>(1, std::min<long long>((items + block - 1) / block, static_cast<long long>(chip_cus) * 8)))); };
+    auto launch = [&](const char* name, auto kernel, dim3 grid, dim3 block, size_t lds, auto... args) {
+      be.begin(name, 0.0);
+      be.launch_kernel_lds(kernel, grid, block, lds, args...);
+      be.end();
+    };
+    constexpr int kItems = 1 + 4 * NX + 4 * NU + NX + NU;
+    const size_t tb_bytes = TB::doubles(N) * sizeof(double);
+    int solve_cols = 32;                                  // identity columns per workgroup of LLT::solve: their vectors must fit the LDS
+    while (solve_cols > 1 && 2 * static_cast<size_t>(m) * (solve_cols + 1) * sizeof(double) > 150 * 1024) solve_cols /= 2;
+    while (solve_cols > 4 && (m + solve_cols - 1) / solve_cols < chip_cus / 8) solve_cols /= 2;     // (few columns per workgroup: the backward substitution is one lane per column)
+    const size_t solve_bytes = 2 * static_cast<size_t>(m) * (solve_cols + 1) * sizeof(double);     // the columns' vectors + the products of the backward substitution
+    auto stage_sums = [&](const double* Xs, const double* Us, int planes, bool ignore_stop) {
+      launch("dense_objective", dc_stage_sums<M>, grid_for(static_cast<long long>(planes) * (T + 1), 64), dim3(64), 0, w, d, P, Xs, Us, planes, ignore_stop);
+    };
+    auto linearise = [&](long long fd_items) {            // tables -> prefix -> every finite difference of the summed cost at S->t
+      launch("dense_tables", dc_tables<M>, grid_for(static_cast<long long>(N) * kItems, 64), dim3(64), 0, w, d, P);
+      launch("dense_prefix", dc_prefix, dim3(1), dim3(64), 0, w, N);
+      launch("dense_fd", dc_fd<M>, grid_for(fd_items, 256), dim3(256), tb_bytes, w, d, P);
+    };
+    auto symmetrise = [&]() {
+      launch("dense_symmetrise", dc_symmetrise, grid_for(static_cast<long long>(n2), 256), dim3(256), 0, w, n, 0);
+      launch("dense_symmetrise", dc_symmetrise, grid_for(static_cast<long long>(n2), 256), dim3(256), 0, w, n, 1);
+      launch("dense_step_end", dc_step_end, dim3(1), dim3(64), 0, w, T);
+    };
+    auto gemm_tiles = [&](int mm, int nn) { return dim3(static_cast<unsigned>(std::max(1, ((mm + 63) / 64) * ((nn + 63) / 64)))); };
+
+    *w.host_word = 0;
+    launch("dense_init", dc_init<M>, grid_for(static_cast<long long>(nUg) + n, 256), dim3(256), 0, w, d, static_cast<const double*>(x0));
+    launch("dense_rollout", dc_rollout<M>, grid_for(N, 64), dim3(64), 0, w, d, dt, P);
+    stage_sums(w.Xg, w.Ug, 1, true);
+    launch("dense_merit", dc_initial_merit, dim3(1), dim3(64), 0, w, T);
+    int iterations = 0; bool done = false;
+    for (int iter = 0; iter < max_iterations && !done; ++iter) {
+      launch("dense_begin", dc_begin_iteration, dim3(1), dim3(64), 0, w, T, iter, max_ms);
+      linearise(static_cast<long long>(n) + static_cast<long long>(n2));                              // terminal boundary (ilqr.hpp:92-102)
+      symmetrise();
+      for (int t = T - 1; t >= 0; --t) {
+        linearise(static_cast<long long>(n) + m + static_cast<long long>(n2) + static_cast<long long>(m2) + static_cast<long long>(mn));
+        launch("dense_assemble", dc_assemble1<NX, NU>, grid_for(static_cast<long long>(n) + m + n2 + mn, 256), dim3(256), 0, w, N);
+        launch("dense_assemble", dc_assemble2<NX, NU>, grid_for(static_cast<long long>(n2) + mn + m2, 256), dim3(256), 0, w, N);
+        launch("dense_ladder", dc_ladder, dim3(kDenseChipRungs), dim3(m <= 64 ? 64 : m <= 128 ? 128 : m <= 256 ? 256 : 512), static_cast<size_t>(kDcPanel) * m * sizeof(double), w, m);
+        launch("dense_solve", dc_solve, dim3(static_cast<unsigned>((m + solve_cols - 1) / solve_cols)), dim3(m <= 64 ? 64 : m <= 128 ? 128 : m <= 256 ? 256 : 512), solve_bytes, w, m, solve_cols);
+        launch("dense_gain", dc_gain_k, grid_for(m, 64), dim3(64), 0, w, m);
+        double* Kt = w.K + static_cast<size_t>(t) * mn;
+        launch("dense_gemm", dc_gemm<false, true>, gemm_tiles(m, n), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(w.inv), static_cast<const double*>(w.qux), Kt, m, m, n);   // K = -Quu^-1 q_ux
+        launch("dense_gemm", dc_gemm<true, false>, gemm_tiles(n, m), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(Kt), static_cast<const double*>(w.quu), w.KtQuu, n, m, m);  // K^T q_uu
+        launch("dense_vx", dc_vx, grid_for(n, 64), dim3(64), 0, w, n, m);
+        launch("dense_gemm", dc_gemm<true, false>, gemm_tiles(n, n), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(Kt), static_cast<const double*>(w.qux), w.tmp_xx, n, m, n); // K^T q_ux
+        launch("dense_gemm", dc_gemm<false, false>, gemm_tiles(n, n), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(w.KtQuu), static_cast<const double*>(Kt), w.V3, n, m, n);  // (K^T q_uu) K
+        launch("dense_vxx", dc_vxx, grid_for(static_cast<long long>(n2), 256), dim3(256), 0, w, n);
+        symmetrise();
+      }
+      launch("dense_trials", dc_trials<M>, dim3(kNumAlphas), dim3(512), static_cast<size_t>(2 * n + m) * sizeof(double), w, d, dt, P, clamp,
+             static_cast<const double*>(chip_bounds), static_cast<const double*>(chip_bounds + NU));
+      stage_sums(w.Xt, w.Ut, kNumAlphas, false);
+      launch("dense_accept", dc_accept, dim3(1), dim3(64), 0, w, T, tolerance, max_iterations);
+      launch("dense_commit", dc_commit, grid_for(static_cast<long long>(nXg + nUg), 256), dim3(256), 0, w, T, n, m);
+      // one pinned word per iteration: (iterations << 8) | stop
+      volatile long long* word = w.host_word;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (long long spins = 1;; ++spins) {
+        const long long v = *word;
+        if ((v >> 8) >= iter + 1 || (v & 1)) { iterations = static_cast<int>(v >> 8); done = (v & 1) != 0; break; }
+        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) {
+          try { be.sync(); } catch (...) {}
+          throw std::runtime_error("the literal stacked solve did not finish an iteration within 600 s");
+        }
+      }
+    }
+    launch("dense_handback", dc_handback<M>, grid_for(N, 64), dim3(64), 0, w, d, P, X, U, cost, iters_total, exit_code, reg_events, central);
+    be.d2h(&host_central[0].st, central, sizeof(CentralState));
+    const CentralState& hc = host_central[0].st;
+    central_total = hc.cur_total; last_total_valid = true;
+    stats.solves += 1; stats.agent_iterations += static_cast<long long>(hc.iterations) * d.N; stats.batch_iterations += hc.iterations;
+    if (hc.done) stats.converged_solves += 1;
+    controls_zero = false;
+    initialized = false; rollout_consistent = false;
+    (void)iterations;
+  }
+  DenseChipWs chip{}; bool chip_ready = false; int chip_cus = 256; double* chip_bounds = nullptr;
+  void free_chip_word() { if (chip.host_word) be.free_pinned(chip.host_word); chip.host_word = nullptr; }
+#else
+  void free_chip_word() {}
+#endif
 
   void get_solution(double* Xo, double* Uo, double* co, int32_t* it, int32_t* ex, bool device_ptr) override {
     if (device_ptr) {                  // the layout conversion writes the caller's device buffers directly

@@ -511,13 +511,14 @@ inline void initialize_agents(MultiAgentProblem& problem) {
 
 // ----------------------------------------------------------------------- strategies ------
 // strategies/centralized.hpp:10-39.  The reference stacks all agents into one OCP and finite-differences the SUMMED cost
-// (dense cross-agent Hessians): `Literal` is that solve on the device (mas_hip_run_centralized_dense, <= 64 agents -- it is
-// 4 (N nx)^2 evaluations of the N-agent cost per time step: seconds beyond 16 agents); `Blocked` is the block-diagonal reading that scales
-// (mas_hip_run_centralized, <= 1024 agents; a different number).  `Auto` takes the literal solve
-// up to 16 agents, so that small problems -- the reference's own example defaults to 10 agents -- get the reference's number.
+// (dense cross-agent Hessians): `Literal` is that solve on the device (mas_hip_run_centralized_dense, <= 256 agents: chip-wide
+// launches, 0.4 s at 64 agents and 6 s at 256 for H = 100); `Blocked` is the block-diagonal reading that scales
+// (mas_hip_run_centralized, <= 1024 agents, a millisecond at 256; a different number).  `Auto` takes the
+// literal solve -- the reference's own number -- up to 64 agents (the reference's example defaults to 10) and the reading that
+// scales beyond.
 struct CentralizedStrategy {
   enum class Reading { Auto, Literal, Blocked };
-  static constexpr int kLiteralMaxAgents = 16;
+  static constexpr int kLiteralMaxAgents = 64;
   Solver solver;
   Reading reading = Reading::Auto;
   explicit CentralizedStrategy(Solver s, Reading r = Reading::Auto) : solver(std::move(s)), reading(r) {}

@@ -18,6 +18,10 @@
  * independent OUTPUT ENTRIES; every entry keeps its own sum over k from 0.0 in index order.
  * tests/test_centralized_readings.py holds this against mas_run_centralized_dense (np.array_equal) at the sizes both can run. */
 
+/* OpenMP only where a loop is worth a parallel region (stacked state dimension >= 64), and never more than 16 threads: a solve enters
+ * tens of thousands of regions, and a box that shows more cores than it grants turns every region's barrier into a time slice */
+static int g_dense_par = 0;
+
 typedef struct {
   int N, T, nx, nu, n, m;
   mas_ocp** o;
@@ -45,7 +49,7 @@ static inline double dchain2(const dstack* s, int ba, double va, int bb, double 
 /* cost tables of one time step (terminal: t == T, controls unused) */
 static void dtables(dstack* s, const double* xg, const double* ug, int t) {
   const int N = s->N, nx = s->nx, nu = s->nu, term = t == s->T;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
   for (int b = 0; b < N; ++b) {
     const mas_ocp* o = s->o[b];
     const double* x = xg + (size_t)b * nx; const double* u = term ? NULL : ug + (size_t)b * nu;
@@ -78,7 +82,7 @@ static void dhessian(const dstack* s, const double* xg, const double* ug, int t,
   const double eps = 1e-5;
   const double* tab = which ? s->cu5 : s->cx5;
   const double f0 = dsafe(s->pre[N]);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (g_dense_par)
   for (int bi = 0; bi < N; ++bi) {
     const mas_ocp* o = s->o[bi];
     const double* x = xg + (size_t)bi * nx; const double* u = term ? NULL : ug + (size_t)bi * nu;
@@ -121,7 +125,7 @@ static void dcross(const dstack* s, const double* xg, const double* ug, int t, d
   const int N = s->N, nx = s->nx, nu = s->nu, n = s->n, m = s->m;
   const double eps = 1e-6;
   (void)n;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (g_dense_par)
   for (int bi = 0; bi < N; ++bi) {                                       /* control coordinate i = (bi, ki) */
     const mas_ocp* o = s->o[bi];
     double xp[16], up[16];
@@ -151,7 +155,7 @@ static void dcross(const dstack* s, const double* xg, const double* ug, int t, d
 static void dgradient(const dstack* s, int which, double* g) {
   const int N = s->N, per = which ? s->nu : s->nx;
   const double eps = 1e-6; const double* tab = which ? s->cu6 : s->cx6;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
   for (int b = 0; b < N; ++b)
     for (int k = 0; k < per; ++k) {
       const double fp = dchain(s, b, tab[((size_t)b * per + k) * 2 + 0], -1, 0.0), fm = dchain(s, b, tab[((size_t)b * per + k) * 2 + 1], -1, 0.0);
@@ -161,7 +165,7 @@ static void dgradient(const dstack* s, int which, double* g) {
 
 /* ---- dense helpers with OpenMP over output entries; every entry: s = 0; s += a * b over k in index order ---- */
 static void par_AtB(const double* A, int p, int m, const double* B, int n, double* C) {     /* C(m x n) = A^T B, A stored p x m */
-#pragma omp parallel for schedule(static) collapse(2)
+#pragma omp parallel for schedule(static) collapse(2) if (g_dense_par)
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < m; ++i) {
       const double* a = A + (size_t)i * p; const double* b = B + (size_t)j * p;
@@ -171,7 +175,7 @@ static void par_AtB(const double* A, int p, int m, const double* B, int n, doubl
     }
 }
 static void par_AB(const double* A, int m, int p, const double* B, int n, double* C) {      /* C(m x n) = A B, A stored m x p */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
   for (int j = 0; j < n; ++j) {
     double* c = C + (size_t)j * m; const double* b = B + (size_t)j * p;
     for (int i = 0; i < m; ++i) c[i] = 0.0;
@@ -189,7 +193,7 @@ static int par_llt_compute(double* M, int n, double* acc) {
     const int rows = n - k - 1;
     if (rows <= 0) continue;
     double* col = M + (size_t)k * n;
-#pragma omp parallel if ((long)rows * k > 20000)
+#pragma omp parallel if (g_dense_par && (long)rows * k > 20000)
     {
 #ifdef _OPENMP
       const int nt = omp_get_num_threads(), id = omp_get_thread_num();
@@ -205,7 +209,7 @@ static int par_llt_compute(double* M, int n, double* acc) {
   return 0;
 }
 static void par_llt_solve_identity(const double* L, int n, double* Inv) {
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) if (g_dense_par)
   for (int c = 0; c < n; ++c) {
     double* o = Inv + (size_t)c * n;
     for (int i = 0; i < n; ++i) o[i] = (i == c) ? 1.0 : 0.0;
@@ -226,9 +230,9 @@ static void par_llt_solve_identity(const double* L, int n, double* Inv) {
   }
 }
 static void par_symmetrise(double* V, int n) {           /* symmetrise_inplace, default variant: two phases give the serial loop's numbers */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
   for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) V[(size_t)j * n + i] = 0.5 * (V[(size_t)j * n + i] + V[(size_t)i * n + j]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
   for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) V[(size_t)j * n + i] = 0.5 * (V[(size_t)j * n + i] + V[(size_t)i * n + j]);
 }
 
@@ -239,6 +243,11 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
   const double dt = ocps[0]->dt;
   const size_t n2 = (size_t)n * n, m2 = (size_t)m * m, mn = (size_t)m * n;
   dstack s; memset(&s, 0, sizeof(s));
+  g_dense_par = n >= 64;
+#ifdef _OPENMP
+  const int threads_before = omp_get_max_threads();
+  if (threads_before > 16) omp_set_num_threads(16);
+#endif
   s.N = N; s.T = T; s.nx = nx; s.nu = nu; s.n = n; s.m = m; s.o = ocps;
   s.c = dalloc((size_t)N); s.pre = dalloc((size_t)N + 1);
   s.cx5 = dalloc((size_t)N * nx * 2); s.cx6 = dalloc((size_t)N * nx * 2); s.cu5 = dalloc((size_t)N * nu * 2); s.cu6 = dalloc((size_t)N * nu * 2);
@@ -252,14 +261,14 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
   const int all_bounds = ({ int ab = 1; for (int b = 0; b < N; ++b) ab &= ocps[b]->has_input_lower && ocps[b]->has_input_upper; ab; });
 
   /* build_global_ocp + initialize_problem: stacked x0, zero controls, rollout, objective (multi_agent_problem.hpp:52-127, ocp.hpp:102-183) */
-#define D_ROLLOUT(Xs, Us) do { _Pragma("omp parallel for schedule(static)") for (int b = 0; b < N; ++b) \
+#define D_ROLLOUT(Xs, Us) do { _Pragma("omp parallel for schedule(static) if (g_dense_par)") for (int b = 0; b < N; ++b) \
     for (int t = 0; t < T; ++t) mas_integrate_rk4(ocps[b], (Xs) + (size_t)t * n + (size_t)b * nx, (Us) + (size_t)t * m + (size_t)b * nu, dt, (Xs) + (size_t)(t + 1) * n + (size_t)b * nx); } while (0)
   for (int b = 0; b < N; ++b) memcpy(x + (size_t)b * nx, ocps[b]->initial_state, sizeof(double) * nx);
   memset(u, 0, sizeof(double) * T * m);
   D_ROLLOUT(x, u);
   /* compute_trajectory_cost on the stacked problem: stage sums (block order) added in t order, then the terminal sum */
   double* gs = dalloc((size_t)T + 1);
-#define D_OBJECTIVE(Xs, Us, out) do { _Pragma("omp parallel for schedule(static)") for (int t = 0; t <= T; ++t) { double cc = 0.0; \
+#define D_OBJECTIVE(Xs, Us, out) do { _Pragma("omp parallel for schedule(static) if (g_dense_par)") for (int t = 0; t <= T; ++t) { double cc = 0.0; \
       for (int b = 0; b < N; ++b) cc += t < T ? ocps[b]->stage_cost(ocps[b], (Xs) + (size_t)t * n + (size_t)b * nx, (Us) + (size_t)t * m + (size_t)b * nu, (size_t)t) \
                                               : ocps[b]->terminal_cost(ocps[b], (Xs) + (size_t)T * n + (size_t)b * nx); gs[t] = cc; } \
     double tot = 0.0; for (int t = 0; t < T; ++t) tot += gs[t]; tot += gs[T]; (out) = tot; } while (0)
@@ -283,7 +292,7 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
     for (int t = T - 1; t >= 0; --t) {
       const double* xs = x + (size_t)t * n; const double* us = u + (size_t)t * m;
       /* linearisation of the stacked problem through the FD hooks (ilqr.hpp:106-113) */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
       for (int b = 0; b < N; ++b) {
         mas_fd_dynamics_state_jacobian(ocps[b], xs + (size_t)b * nx, us + (size_t)b * nu, Ab + (size_t)b * nx * nx);
         mas_fd_dynamics_control_jacobian(ocps[b], xs + (size_t)b * nx, us + (size_t)b * nu, Bb + (size_t)b * nx * nu);
@@ -294,19 +303,19 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
       dcross(&s, xs, us, t, lux);
 
       /* assemble_q (ilqr.hpp:115-119) with the block structure of A and B */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
       for (int i = 0; i < n; ++i) {
         const int b = i / nx, ki = i % nx; const double* a = Ab + (size_t)b * nx * nx + (size_t)ki * nx;
         double sx = 0.0; for (int r = 0; r < nx; ++r) sx += a[r] * vx[(size_t)b * nx + r];
         qx[i] = lx[i] + sx;
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
       for (int i = 0; i < m; ++i) {
         const int b = i / nu, ki = i % nu; const double* bc = Bb + (size_t)b * nx * nu + (size_t)ki * nx;
         double su = 0.0; for (int r = 0; r < nx; ++r) su += bc[r] * vx[(size_t)b * nx + r];
         qu[i] = lu[i] + su;
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
       for (int j = 0; j < n; ++j) {
         for (int i = 0; i < n; ++i) {                                    /* tmp_xx = A^T V */
           const int b = i / nx, ki = i % nx; const double* a = Ab + (size_t)b * nx * nx + (size_t)ki * nx;
@@ -319,7 +328,7 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
           tmp_ux[(size_t)j * m + i] = sv;
         }
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
       for (int j = 0; j < n; ++j) {
         const int bj = j / nx, kj = j % nx; const double* a = Ab + (size_t)bj * nx * nx + (size_t)kj * nx;
         for (int i = 0; i < n; ++i) {                                    /* q_xx = l_xx + (A^T V) A */
@@ -331,7 +340,7 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
           qux[(size_t)j * m + i] = lux[(size_t)j * m + i] + sv;
         }
       }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
       for (int j = 0; j < m; ++j) {
         const int bj = j / nu, kj = j % nu; const double* bc = Bb + (size_t)bj * nx * nu + (size_t)kj * nx;
         for (int i = 0; i < m; ++i) {                                    /* q_uu = l_uu + (B^T V) B */
@@ -378,13 +387,13 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
         const double* xtt = xt + (size_t)t * n; double* utt = ut + (size_t)t * m;
         for (int i = 0; i < n; ++i) dx[i] = xtt[i] - x[(size_t)t * n + i];
         const double* Kt = K + (size_t)t * mn; const double* kt = k + (size_t)t * m;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
         for (int i = 0; i < m; ++i) {
           double kd = 0.0; for (int c = 0; c < n; ++c) kd += Kt[(size_t)c * m + i] * dx[c];
           utt[i] = (u[(size_t)t * m + i] + alpha * kt[i]) + kd;
         }
         if (all_bounds) for (int b = 0; b < N; ++b) mas_clamp_controls_column(ocps[b], utt + (size_t)b * nu);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (g_dense_par)
         for (int b = 0; b < N; ++b) mas_integrate_rk4(ocps[b], xtt + (size_t)b * nx, utt + (size_t)b * nu, dt, xt + (size_t)(t + 1) * n + (size_t)b * nx);
       }
       ++trials;
@@ -411,6 +420,9 @@ double mas_run_centralized_dense_structured(mas_ocp** ocps, int N, int max_itera
     stats->reg_events += reg_events; stats->trials += trials;
     for (int q = 0; q < 12; ++q) stats->alpha_hist[q] += alpha_hist[q];
   }
+#ifdef _OPENMP
+  omp_set_num_threads(threads_before);
+#endif
 #undef D_ROLLOUT
 #undef D_OBJECTIVE
   double* all[] = {s.c, s.pre, s.cx5, s.cx6, s.cu5, s.cu6, x, u, xt, ut, Ab, Bb, lx, lu, lxx, luu, lux, k, K, V, vx, qx, qu, qxx, qux, quu, quu_reg,

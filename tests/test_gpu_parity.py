@@ -164,14 +164,41 @@ def test_golden_fixtures_on_the_gpu(gpu_lib):
 
 
 @pytest.mark.parametrize("N,T", [(2, 10), (4, 10), (10, 10), (16, 12), (3, 40)])
-def test_centralized_dense_literal_stacked_solve(gpu_lib, oracle, N, T):
+@pytest.mark.parametrize("chip", [1, 0])
+def test_centralized_dense_literal_stacked_solve(gpu_lib, oracle, N, T, chip):
     """mas_hip_run_centralized_dense: the reference's LITERAL centralised strategy -- one iLQR on the stacked OCP, finite
     differences of the summed cost, dense cross-agent Hessians, dense LLT and gains (centralized.hpp:18-38,
-    multi_agent_problem.hpp:52-127) -- bit-equal to the oracle's dense restatement up to its limit of 16 agents."""
+    multi_agent_problem.hpp:52-127) -- bit-equal to the oracle's PLAIN dense restatement (mas_ilqr_solve on the stacked OCP through
+    the generic FD hooks), as chip-wide launches with exact re-use (csrc/mas_dense_chip.hpp) and in the one-workgroup form."""
     x0 = oracle.single_track_x0(N)
-    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "centralized_dense")
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "centralized_dense", options={"dense_chip": chip})
     o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy="centralized_dense")
     _same(e, o)
+
+
+@pytest.mark.parametrize("model,N,T,dt", [("MODEL_PENDULUM", 2, 12, 0.05), ("MODEL_LQR_IDENTITY", 3, 10, 0.1), ("MODEL_BICYCLE6", 2, 8, 0.1),
+                                          ("MODEL_SINGLE_TRACK_LANE", 5, 20, 0.1), ("MODEL_SINGLE_TRACK", 7, 30, 0.5)])
+def test_centralized_dense_chip_other_models(gpu_lib, oracle, model, N, T, dt):
+    """the chip-wide literal solve on the other workloads (non-trivial terminal cost, analytic hooks that the stacked OCP does NOT
+    inherit, six states, perturbed and clamped agents, a budget of iterations): against the plain restatement, the structured one and
+    the one-workgroup form"""
+    mid = getattr(oracle, model)
+    nx, nu, _ = oracle.model_dims(mid)
+    rng = np.random.default_rng(5)
+    if model == "MODEL_PENDULUM":
+        x0 = np.array([[math.pi - 0.05, 0.0], [math.pi - 0.1, 0.1]])
+    elif nx == 4 and model != "MODEL_LQR_IDENTITY":
+        x0 = oracle.single_track_x0(N) + 0.05 * rng.standard_normal((N, 4))
+    else:
+        x0 = np.tile(np.eye(nx)[0], (N, 1)) + 0.1 * np.arange(N)[:, None] + (np.array([0, 0, 0, 2.0, 0, 0])[None, :nx] if nx == 6 else 0)
+    kw = dict(max_iterations=6) if model == "MODEL_SINGLE_TRACK" else {}
+    e = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized_dense", **kw)
+    one = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized_dense", options={"dense_chip": 0}, **kw)
+    for key in ("cost", "X", "U", "iters"):
+        assert np.array_equal(e[key], one[key]), key
+    assert e["total_cost"] == one["total_cost"] and e["stats"]["reg_events"] == one["stats"]["reg_events"]
+    for strategy in ("centralized_dense", "centralized_dense_structured"):
+        _same(e, oracle.solve_batch(mid, x0, None, T, dt, strategy=strategy, **kw))
 
 
 def test_centralized_against_the_dense_stacked_goldens(gpu_lib):
@@ -423,7 +450,9 @@ def test_maximum_sizes(gpu_lib, oracle):
     with pytest.raises(MasHipError):
         run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(1025), None, 5, 0.5, "centralized")
     with pytest.raises(MasHipError):
-        run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(65), None, 5, 0.5, "centralized_dense")
+        run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(257), None, 5, 0.5, "centralized_dense")
+    with pytest.raises(MasHipError):
+        run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(65), None, 5, 0.5, "centralized_dense", options={"dense_chip": 0})
     N, T = 65536, 100
     x0 = oracle.single_track_x0(N)
     e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, "sequential", max_outer=2)
@@ -520,32 +549,57 @@ def test_fused_round_agrees_across_the_line_search_forms(gpu_lib, oracle, model,
     assert new["iters"][sample].tolist() == o["iters"].tolist()
 
 
-@pytest.mark.parametrize("N", [2, 8, 16, 32])
+@pytest.mark.parametrize("N", [2, 8, 16, 32, 64])
 def test_both_centralised_readings_at_config2s_horizon(gpu_lib, oracle, N):
-    """C2's horizon (H = 100): the reference's literal stacked solve on the device (<= 64 agents; 7 s at 32) is bit-equal to the oracle's dense
-    restatement, the block-diagonal reading to the oracle's blocked one; how far the two readings lie apart there -- tens of per
-    cent, inside the literal solve's own one-ulp band -- is tests/test_centralized_readings.py (CPU) and bench.py's C2 parity block"""
+    """C2's horizon (H = 100): the reference's literal stacked solve on the device is bit-equal to the oracle's dense restatement (the plain
+    one up to 16 agents, where it needs seconds; the structured one -- the same numbers, tests/test_centralized_structured.py -- at every
+    size), the block-diagonal reading to the oracle's blocked one; how far the two readings lie apart there -- tens of per cent, inside
+    the literal solve's own one-ulp band -- is tests/test_centralized_readings.py (CPU) and bench.py's C2 parity block"""
     x0 = oracle.single_track_x0(N)
     for strategy in ("centralized_dense", "centralized"):
         e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy)
-        o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy=strategy)
-        assert np.array_equal(e["cost"], o["cost"]) and np.array_equal(e["X"], o["X"]) and np.array_equal(e["U"], o["U"]), strategy
-        assert e["iters"].tolist() == o["iters"].tolist() and e["stats"]["reg_events"] == o["stats"]["reg_events"]
-        assert abs(e["total_cost"] - o["total_cost"]) <= 1e-12 * abs(o["total_cost"])
+        against = [strategy] if strategy == "centralized" else (["centralized_dense_structured"] + (["centralized_dense"] if N <= 16 else []))
+        for name in against:
+            o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy=name)
+            assert np.array_equal(e["cost"], o["cost"]) and np.array_equal(e["X"], o["X"]) and np.array_equal(e["U"], o["U"]), name
+            assert e["iters"].tolist() == o["iters"].tolist() and e["stats"]["reg_events"] == o["stats"]["reg_events"]
+            if strategy == "centralized":
+                assert abs(e["total_cost"] - o["total_cost"]) <= 1e-12 * abs(o["total_cost"])
+            else:
+                assert e["total_cost"] == o["total_cost"]
 
 
-def test_literal_centralised_solve_at_64_agents(gpu_lib, oracle):
-    """The literal stacked solve at 64 agents, H = 100 (one workgroup: about a minute).  The oracle needs three minutes per solve there, so the
-    comparison is with the committed oracle curve (profiles/r3_c2_readings_curve.json, tools/c2_readings_curve.py; its rows up to 16 agents
-    are pinned to a fresh computation by tests/test_centralized_readings.py): total cost and iteration count of both readings."""
+def test_literal_centralised_solve_against_the_committed_curve(gpu_lib, oracle):
+    """The committed oracle curve (profiles/r3_c2_readings_curve.json, the PLAIN restatement: 99 s / 17 minutes of a core at 32 / 64 agents; its
+    rows up to 16 agents are pinned to a fresh computation by tests/test_centralized_readings.py): total cost and iteration count of both
+    readings on the device."""
     import json
-    row = next(r for r in json.load(open(os.path.join(ROOT, "profiles", "r3_c2_readings_curve.json")))["curve"] if r["agents"] == 64)
-    x0 = oracle.single_track_x0(64)
-    for strategy, total, iterations in (("centralized_dense", row["literal_total_cost"], row["iterations_literal"]),
-                                        ("centralized", row["block_diagonal_total_cost"], row["iterations_block_diagonal"])):
-        e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy)
-        assert abs(e["total_cost"] - total) <= 1e-12 * abs(total), (strategy, e["total_cost"], total)
-        assert int(e["iters"][0]) == iterations, strategy
+    rows = {r["agents"]: r for r in json.load(open(os.path.join(ROOT, "profiles", "r3_c2_readings_curve.json")))["curve"]}
+    for n in (32, 64):
+        row = rows[n]
+        x0 = oracle.single_track_x0(n)
+        for strategy, total, iterations in (("centralized_dense", row["literal_total_cost"], row["iterations_literal"]),
+                                            ("centralized", row["block_diagonal_total_cost"], row["iterations_block_diagonal"])):
+            e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, 100, 0.5, strategy)
+            assert abs(e["total_cost"] - total) <= (0.0 if strategy == "centralized_dense" else 1e-12 * abs(total)), (strategy, e["total_cost"], total)
+            assert int(e["iters"][0]) == iterations, strategy
+
+
+@pytest.mark.parametrize("N", [128, 256])
+def test_literal_centralised_solve_at_config2s_size(gpu_lib, oracle, N):
+    """BASELINE configs[1] -- 256 agents, H = 100 -- under the reference's LITERAL algorithm: n = 1024 stacked states, m = 512 stacked controls,
+    eight iterations of a dense Riccati recursion, 6 s on the device.  The oracle's structured restatement needs ten minutes of eight cores
+    there, so the comparison is with its committed vectors (tests/golden/centralized_dense_large.json, tools/make_dense_goldens.py):
+    per-agent costs and the total bit for bit, SHA-256 of the trajectories and controls, iterations, rungs of the ladder."""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "centralized_dense_large.json")))["cases"][str(N)]
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(N), None, g["horizon"], g["dt"], "centralized_dense")
+    assert float(e["total_cost"]).hex() == g["total_cost"]
+    assert [float(v).hex() for v in e["cost"]] == g["cost"]
+    assert int(e["iters"][0]) == g["iterations"] and e["stats"]["reg_events"] == g["reg_events"]
+    assert hashlib.sha256(np.ascontiguousarray(e["X"]).tobytes()).hexdigest() == g["sha256_X"]
+    assert hashlib.sha256(np.ascontiguousarray(e["U"]).tobytes()).hexdigest() == g["sha256_U"]
 
 
 @pytest.mark.parametrize("model,N,T", [("MODEL_SINGLE_TRACK", 10, 30), ("MODEL_SINGLE_TRACK", 70, 40), ("MODEL_SINGLE_TRACK", 600, 25),
