@@ -36,6 +36,10 @@ struct FusedRound {
   const int* slot_prev = nullptr; // [Np] that slot
   double* D_dump = nullptr;       // staged access (parity tests): the tiles also go to the global tile array
   int* error = nullptr;           // raised when a bounded wait gives up
+  // chained trust-region strategy (TRUST instantiation): the epilogue of every agent whose solve ended in the select above runs in this
+  // kernel, before anything is linearised (fused_trust_phase)
+  TrustState ts{};
+  double* X_old = nullptr; double* U_old = nullptr; const double* x0 = nullptr; double dt = 0.0;
 };
 
 constexpr int kFusedAgents = 16;            // agents per workgroup: four backward wavefronts of four agents
@@ -49,6 +53,12 @@ struct FusedCtl {
   int any_act, any_pend;
   int pad0;
   int parts_done;                // helpers that have written their blocks of chunk 0
+  // trust-region epilogue (TRUST): the agent's solve ended in this round's select; its trajectory comes back from the OLD planes (revert);
+  // what the helpers store to X, U also goes to the old planes (accept); its step leaves the radius (re-roll), scaled by scale[]
+  int ended[kFusedAgents], from_old[kFusedAgents], dup[kFusedAgents], reroll[kFusedAgents];
+  int any_ended, any_dup, rcount, rnext;   // rlist[0 .. rcount-1]: the group of re-rolling agents at work; rnext: where the next group starts
+  int rlist[kFusedAgents];
+  double scale[kFusedAgents];
 };
 
 template <class M, int HELPERS, int RING>
@@ -411,6 +421,97 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
   if (valid && lane == 0) reg_events[a] += regs;
 }
 
+// ---- trust-region epilogue of the agents whose solve ended in this round's select (detail::run_trust_region, nash.hpp:214-243), all
+// threads of the workgroup, before the helpers and the recursion start.  The same statements as mas_trust_epilogue_kernel /
+// TrustNormBody / TrustRerollBody / TrustCopyBody of the five-kernel round:
+//   * step norm: the squared differences of all 16 agents side by side, their sums serially in the reference's column-major order
+//     (one lane per agent);
+//   * a step inside the radius is accepted (cost < old cost: radius x1.5, the new trajectory becomes the old one) or reverted
+//     (radius x0.5) at once -- and costs NO copy pass: the helpers, which store the accepted trial to X, U while they linearise, store
+//     it to the old planes as well (dup), or take the agent's trajectory from the old planes instead of the trial (from_old);
+//   * a step that leaves the radius is scaled back and rolled out by dependency levels (mas_kernel_levels.hpp, all threads of the
+//     workgroup, ~10 us per agent), re-costed, accepted or reverted.
+// LDS: the ring, idle until the helpers start.
+template <class M, class FL>
+__device__ __forceinline__ void fused_trust_phase(const Dims& d, const ModelParams& P, double* lds, FusedCtl* ctl, int a_base,
+                                                  double* __restrict__ X, double* __restrict__ U, const FusedRound& fr) {
+  constexpr int NX = M::NX, NU = M::NU;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x), T = d.T, R = T * NU, RS = R | 1;
+  double* scratch = lds + FL::oRing;
+  auto u_new = [&](int al, int r) {                                     // the controls the solve ended with: its last accepted trial, else U
+    const int jsel = ctl->selj[al];
+    return jsel >= 0 ? (fr.Us + (static_cast<size_t>(jsel) * T * NU + r) * d.Np)[static_cast<unsigned>(ctl->col[al])] : MAS_AT(U, r, a_base + al);
+  };
+  for (int e = tid; e < kFusedAgents * R; e += nt) {
+    const int al = e & (kFusedAgents - 1), r = e >> 4;
+    if (ctl->ended[al]) { const double dl = u_new(al, r) - MAS_AT(fr.U_old, r, a_base + al); scratch[al * RS + r] = dl * dl; }
+  }
+  __syncthreads();
+  if (tid < kFusedAgents && ctl->ended[tid]) {
+    const int a = a_base + tid;
+    const double norm = sqrt(lds_serial_sum(scratch + tid * RS, R));    // delta.norm(): Frobenius, column-major order (nash.hpp:216-217)
+    const double radius = fr.ts.radii[a];
+    if (norm > radius) { ctl->reroll[tid] = 1; ctl->scale[tid] = radius / norm; }
+    else {
+      const bool accept = fr.ts.cost[a] < fr.ts.cost_old[a];
+      fr.ts.finish(a, fr.ts.cost[a], radius);                           // accept / revert, nash.hpp:228-243
+      if (accept) ctl->dup[tid] = 1; else ctl->from_old[tid] = 1;
+    }
+  }
+  __syncthreads();
+  // the agents whose step leaves the radius, in groups of as many as the ring holds (xs | inc | uc | misc per agent)
+  const size_t per = static_cast<size_t>(NX) * (T + 1) + static_cast<size_t>(NX) * T + R + 8;
+  const int gmax = static_cast<int>((static_cast<size_t>(FL::oCtl - FL::oRing)) / per);
+  if (tid == 0) ctl->rnext = 0;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      int G0 = 0, al = ctl->rnext;
+      for (; al < kFusedAgents && G0 < gmax; ++al) { if (ctl->reroll[al]) ctl->rlist[G0++] = al; }
+      ctl->rcount = G0; ctl->rnext = al;
+    }
+    __syncthreads();
+    const int G = ctl->rcount;                                          // (uniform)
+    if (G == 0) break;
+    const int* list = ctl->rlist;
+    for (int e = tid; e < G * R; e += nt) {
+      const int g = e / R, r = e - g * R, al = list[g], a = a_base + al;
+      const double o = MAS_AT(fr.U_old, r, a);
+      (scratch + g * per + NX * (T + 1) + NX * T)[r] = o + ctl->scale[al] * (u_new(al, r) - o);          // cand_u = old_u + scale * delta
+    }
+    if (tid < G * NX) { const int g = tid / NX, i = tid - g * NX; (scratch + g * per)[i * (T + 1)] = MAS_AT(fr.x0, i, a_base + list[g]); }
+    __syncthreads();
+    levels_rollout_cost_group<M>(scratch, per, G, T, fr.dt, P, tid, nt);                                   // cand_x = rollout; cand_cost = objective (nash.hpp:219-226)
+    if (tid < G) {
+      const int a = a_base + list[tid];
+      double* misc = scratch + tid * per + NX * (T + 1) + NX * T + R;
+      const double c = misc[3];
+      misc[4] = (c < fr.ts.cost_old[a]) ? 1.0 : 0.0;
+      fr.ts.finish(a, c, fr.ts.radii[a]);
+      if (misc[4] != 0.0) { ctl->selj[list[tid]] = -1; ctl->col[list[tid]] = a; }      // accepted: nothing pending any more, the helpers read X, U
+      else ctl->from_old[list[tid]] = 1;
+    }
+    __syncthreads();
+    for (int e = tid; e < G * (T + 1) * NX; e += nt) {                  // accepted: the re-rolled trajectory is the current AND the old one
+      const int g = e / ((T + 1) * NX), q = e - g * (T + 1) * NX, a = a_base + list[g];
+      const double* xs = scratch + g * per;
+      if (xs[NX * (T + 1) + NX * T + R + 4] != 0.0) { const double v = xs[(q % NX) * (T + 1) + q / NX]; MAS_AT(X, q, a) = v; MAS_AT(fr.X_old, q, a) = v; }
+    }
+    for (int e = tid; e < G * R; e += nt) {
+      const int g = e / R, r = e - g * R, a = a_base + list[g];
+      const double* xs = scratch + g * per;
+      if (xs[NX * (T + 1) + NX * T + R + 4] != 0.0) { const double v = xs[NX * (T + 1) + NX * T + r]; MAS_AT(U, r, a) = v; MAS_AT(fr.U_old, r, a) = v; }
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {
+    const bool mine = tid < kFusedAgents;
+    const unsigned long long pm = __ballot(mine && (ctl->selj[mine ? tid : 0] >= 0 || ctl->from_old[mine ? tid : 0] != 0)), dm = __ballot(mine && ctl->dup[mine ? tid : 0] != 0);
+    if (tid == 0) { ctl->any_pend = pm != 0ull; ctl->any_dup = dm != 0ull; }
+  }
+  __syncthreads();
+}
+
 // ---- one helper wavefront: commit + linearisation of the workgroup's items, chunk by chunk in reverse time ----
 // The recursion cannot start before chunk 0 (the last four time steps) lies in the ring, and one item is ~1,400 dependent FP64
 // instructions (~6 us for a lone wavefront).  So chunk 0 is SHARED OUT BY BLOCKS of the tile: helper 0 evaluates A and B, helper 1
@@ -427,7 +528,7 @@ struct PartRange {                 // the elements of a tile the blocks in PARTS
     MAS_UNROLL for (int e = lo2; e < hi2; ++e) f(e);
   }
 };
-template <class M, int HELPERS, int RING>
+template <class M, int HELPERS, int RING, bool TRUST>
 __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelParams& P, double* __restrict__ lds, FusedCtl* ctl, int h, int a_base,
                                                   double* __restrict__ X, double* __restrict__ U, const FusedRound& fr) {
   using FL = FusedLayout<M, HELPERS, RING>;
@@ -446,12 +547,15 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
   const int l = static_cast<int>(threadIdx.x) & 63, al = l & 15, dt = l >> 4, a = a_base + al;
   const bool act = ctl->act[al] != 0;
   const int jsel = ctl->selj[al];
-  const bool pend = jsel >= 0;
+  bool from_old = false, dup = false;                                  // trust-region epilogue: reverted to / accepted as the old trajectory
+  if constexpr (TRUST) { from_old = ctl->from_old[al] != 0; dup = ctl->dup[al] != 0; }
+  const bool pend = jsel >= 0 || from_old;
   const bool any_act = ctl->any_act != 0;
-  // where this agent's trajectory lies: the trial plane its select accepted (column = agent or its slot in that round's list), else X, U
-  const double* Xsrc = pend ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * NX * d.Np : X;
-  const double* Usrc = pend ? fr.Us + static_cast<size_t>(jsel) * d.T * NU * d.Np : U;
-  const unsigned col = static_cast<unsigned>(ctl->col[al]);
+  // where this agent's trajectory lies: the old planes (reverted), the trial plane its select accepted (column = agent or its slot in
+  // that round's list), else X, U
+  const double* Xsrc = from_old ? fr.X_old : (jsel >= 0 ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * NX * d.Np : X);
+  const double* Usrc = from_old ? fr.U_old : (jsel >= 0 ? fr.Us + static_cast<size_t>(jsel) * d.T * NU * d.Np : U);
+  const unsigned col = from_old ? static_cast<unsigned>(a) : static_cast<unsigned>(ctl->col[al]);
   double* ring = lds + FL::oRing;
   const int C = (d.T + 3) >> 2;
   auto load_xu = [&](int t, bool wanted, double* x, double* u) {
@@ -463,9 +567,23 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
     }
   };
   auto commit = [&](int t, const double* x, const double* u) {         // x = best_x; u = best_u, ilqr.hpp:231-232
-    MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, t * NX + q, a) = x[q];
-    MAS_UNROLL for (int q = 0; q < NU; ++q) MAS_AT(U, t * NU + q, a) = u[q];
-    if (t == d.T - 1) { MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, d.T * NX + q, a) = (Xsrc + (static_cast<size_t>(d.T) * NX + q) * d.Np)[col]; }
+    if (pend) {
+      MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(X, t * NX + q, a) = x[q];
+      MAS_UNROLL for (int q = 0; q < NU; ++q) MAS_AT(U, t * NU + q, a) = u[q];
+    }
+    if constexpr (TRUST) {                                              // old_x = best_x; old_u = best_u of an accepted outer iteration, nash.hpp:232-236
+      if (dup) {
+        MAS_UNROLL for (int q = 0; q < NX; ++q) MAS_AT(fr.X_old, t * NX + q, a) = x[q];
+        MAS_UNROLL for (int q = 0; q < NU; ++q) MAS_AT(fr.U_old, t * NU + q, a) = u[q];
+      }
+    }
+    if (t == d.T - 1) {
+      MAS_UNROLL for (int q = 0; q < NX; ++q) {
+        const double xT = (Xsrc + (static_cast<size_t>(d.T) * NX + q) * d.Np)[col];
+        if (pend) MAS_AT(X, d.T * NX + q, a) = xT;
+        if constexpr (TRUST) { if (dup) MAS_AT(fr.X_old, d.T * NX + q, a) = xT; }
+      }
+    }
   };
   // the blocks PARTS of chunk 0: elements [lo, hi) of this lane's tile
   auto share_of_first_chunk = [&](auto parts_tag, bool commits) {
@@ -474,8 +592,8 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
     const int t = 4 * (C - 1) + dt;
     const bool in = t < d.T;
     double x[NX], u[NU];
-    load_xu(t, in && (act || pend), x, u);
-    if (commits && in && pend) commit(t, x, u);
+    load_xu(t, in && (act || pend || dup), x, u);
+    if (commits && in && (pend || dup)) commit(t, x, u);
     if (!any_act) return;
     double Dl[ND];
     R::for_each([&](int e) { Dl[e] = 0.0; });
@@ -492,8 +610,8 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
     const int t = 4 * (C - 1 - n) + dt;
     const bool in = t < d.T;
     double x[NX], u[NU];
-    load_xu(t, in && (act || pend), x, u);
-    if (in && pend) commit(t, x, u);
+    load_xu(t, in && (act || pend || dup), x, u);
+    if (in && (pend || dup)) commit(t, x, u);
     if (!any_act) return;                                              // uniform: a workgroup of retired agents only commits
     double Dl[ND];
     if (in && act) linearise<M>(x, u, t, Dl, P);
@@ -540,12 +658,13 @@ __device__ __forceinline__ void fused_commit_wave(const Dims& d, const FusedCtl*
 }
 
 // grid = ceil(N / 16) workgroups of 64 * (4 + HELPERS) threads, FusedLayout::kBytes of dynamic LDS
-template <class M, int HELPERS, int RING>
+template <class M, int HELPERS, int RING, bool TRUST = false>
 __global__ void __launch_bounds__(64 * (4 + HELPERS), HELPERS == 0 ? 1 : 2)   // (with helpers two wavefronts share a SIMD)
 mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, double* __restrict__ U, double* __restrict__ kff, double* __restrict__ Kfb,
                              long long* __restrict__ reg_events, FusedRound fr) {
   using FL = FusedLayout<M, HELPERS, RING>;
   static_assert((RING >= 2 && RING <= 4 && HELPERS >= 1) || (RING == 0 && HELPERS <= 1), "ring of chunk slots");
+  static_assert(!TRUST || (RING > 0 && M::kRolloutLevels > 0), "the trust-region epilogue runs in the helpers' workgroups and re-rolls by dependency levels");
   extern __shared__ double lds[];
   FusedCtl* ctl = reinterpret_cast<FusedCtl*>(lds + FL::oCtl);
   const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
@@ -567,13 +686,24 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
     if (lane == 0) { ctl->any_act = am != 0ull; ctl->any_pend = pm != 0ull; }
     if (lane < 4) { ctl->ready[lane] = 0; ctl->consumed[lane] = 0; }
     if (lane == 0) ctl->parts_done = 0;
+    if constexpr (TRUST) {
+      const int ended = (mine && (sel_outcome == SelectBody::kConverged || sel_outcome == SelectBody::kRetired || (sel_outcome & SelectBody::kChained) != 0)) ? 1 : 0;
+      if (lane < kFusedAgents) { ctl->ended[lane] = ended; ctl->from_old[lane] = 0; ctl->dup[lane] = 0; ctl->reroll[lane] = 0; }
+      const unsigned long long em = __ballot(ended != 0);
+      if (lane == 0) { ctl->any_ended = em != 0ull; ctl->any_dup = 0; }
+    }
   }
   __syncthreads();
   // counters and the next round's live list (two atomics, one of them returning) AFTER the barrier: the helpers are on their
   // first chunk by now, and this wavefront's recursion cannot start before that chunk is there
   if (wave == 0 && fr.do_select) fr.sel.count(sel_outcome, a_base + lane);
+  if constexpr (TRUST) {
+    if (ctl->any_ended) fused_trust_phase<M, FL>(d, P, lds, ctl, a_base, X, U, fr);       // (uniform)
+  }
   const bool any_act = ctl->any_act != 0, any_pend = ctl->any_pend != 0;
-  if (!any_act && !any_pend) return;
+  bool any_dup = false;
+  if constexpr (TRUST) any_dup = ctl->any_dup != 0;
+  if (!any_act && !any_pend && !any_dup) return;
 
   if constexpr (RING == 0) {
     // every derivative analytic: the backward wavefronts evaluate them (AnalyticSource); a fifth wavefront commits
@@ -605,12 +735,14 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
 #endif
     const int jsel = ctl->selj[al0];
     const double* xT_src = (jsel >= 0) ? fr.Xs + static_cast<size_t>(jsel) * (d.T + 1) * M::NX * d.Np : X;
+    unsigned xT_col = static_cast<unsigned>(ctl->col[al0]);
+    if constexpr (TRUST) { if (ctl->from_old[al0]) { xT_src = fr.X_old; xT_col = static_cast<unsigned>(a_base + al0); } }   // (reverted: x_T of the old trajectory)
     const int l16 = lane & 15, i = l16 & 3, j = l16 >> 2;
     RingSource<M, HELPERS, RING> src(lds, ctl, fr.error, wave, al0, d.T, l16, i, j, (i < M::NU) ? i : M::NU - 1, (j < M::NU) ? j : M::NU - 1);
-    fused_backward_wave<M, FL::oBwd, FL::kBwdStride>(d, P, lds, ctl->act[al0] != 0, src, wave, a_base, xT_src, static_cast<unsigned>(ctl->col[al0]), nullptr, kff, Kfb, reg_events);
+    fused_backward_wave<M, FL::oBwd, FL::kBwdStride>(d, P, lds, ctl->act[al0] != 0, src, wave, a_base, xT_src, xT_col, nullptr, kff, Kfb, reg_events);
   } else {
     __builtin_amdgcn_s_setprio(0);
-    fused_helper_wave<M, HELPERS, RING>(d, P, lds, ctl, wave - 4, a_base, X, U, fr);
+    fused_helper_wave<M, HELPERS, RING, TRUST>(d, P, lds, ctl, wave - 4, a_base, X, U, fr);
   }
   }
 }

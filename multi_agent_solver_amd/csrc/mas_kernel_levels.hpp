@@ -96,6 +96,69 @@ __device__ __forceinline__ double levels_rollout_cost(double* xs, double* inc, c
   return misc[3];
 }
 
+// The same for a GROUP of G agents at once (the trust-region epilogue inside the fused round, mas_fused_hip.hpp: up to 16 agents of a
+// workgroup re-roll in the same round): agent g's arrays lie g * stride doubles further on (xs | inc | uc | misc, as above); the items
+// of a pass are (agent, time step), the serial sums run on one lane per (agent, component).  Same statements, same operands, same
+// order per agent: bit-identical to levels_rollout_cost.  Every agent's cost is left in its misc[3].
+template <class M, int LEV>
+__device__ __forceinline__ void levels_pass_group(double* base, size_t stride, int G, int T, double dt, const ModelParams& P, int tid, int nthreads) {
+  constexpr int NX = M::NX, NU = M::NU;
+  for (int e = tid; e < G * T; e += nthreads) {
+    const int g = e / T, t = e - g * T;
+    double* xs = base + g * stride; double* inc = xs + NX * (T + 1); const double* uc = inc + NX * T;
+    double x[NX], u[NU], in[NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = (M::state_level(i) < LEV) ? xs[i * (T + 1) + t] : 0.0;
+    MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = uc[t * NU + i];
+    rk4_increment<M>(x, u, dt, in, P);
+    MAS_UNROLL for (int i = 0; i < NX; ++i) { if (M::state_level(i) == LEV) inc[i * T + t] = in[i]; }
+  }
+  __syncthreads();
+  if (tid < G * NX) {
+    const int g = tid / NX, comp = tid - g * NX;
+    if (M::state_level(comp) == LEV) {
+      double* row = base + g * stride + comp * (T + 1);
+      const double* add = base + g * stride + NX * (T + 1) + comp * T;
+      double v = row[0];
+      int t = 0;
+      for (; t + 8 <= T; t += 8) {
+        double a[8];
+        MAS_UNROLL for (int q = 0; q < 8; ++q) a[q] = add[t + q];
+        MAS_UNROLL for (int q = 0; q < 8; ++q) { v = v + a[q]; row[t + q + 1] = v; }
+      }
+      for (; t < T; ++t) { v = v + add[t]; row[t + 1] = v; }
+    }
+  }
+  __syncthreads();
+}
+template <class M, int... LEV>
+__device__ __forceinline__ void levels_all_group(double* base, size_t stride, int G, int T, double dt, const ModelParams& P, int tid, int nthreads, std::integer_sequence<int, LEV...>) {
+  (levels_pass_group<M, LEV>(base, stride, G, T, dt, P, tid, nthreads), ...);
+}
+template <class M>
+__device__ __forceinline__ void levels_rollout_cost_group(double* base, size_t stride, int G, int T, double dt, const ModelParams& P, int tid, int nthreads) {
+  constexpr int NX = M::NX, NU = M::NU;
+  static_assert(M::kRolloutLevels > 0, "model without dependency levels");
+  levels_all_group<M>(base, stride, G, T, dt, P, tid, nthreads, std::make_integer_sequence<int, M::kRolloutLevels>{});
+  for (int e = tid; e < G * T; e += nthreads) {
+    const int g = e / T, t = e - g * T;
+    const double* xs = base + g * stride; double* inc = base + g * stride + NX * (T + 1); const double* uc = inc + NX * T;
+    double x[NX], u[NU];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = xs[i * (T + 1) + t];
+    MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = uc[t * NU + i];
+    inc[t] = M::stage_cost(x, u, t, P);
+  }
+  __syncthreads();
+  if (tid < G) {
+    const double* xs = base + tid * stride; const double* inc = xs + NX * (T + 1); double* misc = base + tid * stride + NX * (T + 1) + NX * T + T * NU;
+    double c = lds_serial_sum(inc, T);
+    double xT[NX];
+    MAS_UNROLL for (int i = 0; i < NX; ++i) xT[i] = xs[i * (T + 1) + T];
+    c += M::terminal_cost(xT, P);
+    misc[3] = c;
+  }
+  __syncthreads();
+}
+
 // TrustRerollBody (nash.hpp:219-226: scaled step, rollout, cost, accept / revert) by dependency levels, one workgroup per queued agent:
 // the re-roll of the three-kernel epilogue in the rounds in which thousands of solves end (norm and copy stay coalesced kernels over
 // all agents there) -- ~25 us for a few hundred queued agents where the four-lanes-per-rollout chain (mas_trust_reroll_quad_kernel) takes 150.

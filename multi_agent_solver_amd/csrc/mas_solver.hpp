@@ -104,6 +104,7 @@ class SolverBase {
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
+    bool fused_trust = true;                // chained trust-region epilogue inside the fused kernel (four-state FD models); false: the five-kernel round
     bool dense_chip = true;                 // the literal stacked solve as chip-wide launches (mas_dense_chip.hpp); false: one workgroup (mas_dense.hpp, <= 64 agents)
     int central_combine = 1, central_wpb = kCentralWavesPerBlock, central_peek = 1;
     bool set(const std::string& key, long long v) {
@@ -119,6 +120,7 @@ class SolverBase {
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
       else if (key == "dense_chip") dense_chip = v != 0;
+      else if (key == "fused_trust") fused_trust = v != 0;
       else if (key == "central_combine") central_combine = static_cast<int>(v);
       else if (key == "central_peek") central_peek = static_cast<int>(v);
       else if (key == "central_wpb") { if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) central_wpb = static_cast<int>(v); else return false; }
@@ -128,7 +130,7 @@ class SolverBase {
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
       static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
-                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip"};
+                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
         for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
@@ -1093,7 +1095,7 @@ class SolverImpl final : public SolverBase {
     const ForwardBody<M> fwd = make_forward();
 #if !defined(MAS_HOST_EMULATION)
     if constexpr (kFusable) {
-      if (fused_enabled() && !trust_epilogue && !debug) { fused_rounds(n_solves, timed, fwd); return; }
+      if (fused_enabled() && !debug && (!trust_epilogue || fused_trust_fits())) { fused_rounds(n_solves, timed, fwd, trust_epilogue); return; }
     }
 #endif
 #if defined(MAS_HOST_EMULATION)
@@ -1228,18 +1230,36 @@ class SolverImpl final : public SolverBase {
 #endif
   bool fused_enabled() const { return switches.fused && d.N < (1 << 24); }      // (the packed word carries 24-bit agent counts)
   double fused_bytes() const { return sweep_bytes() + backward_bytes(); }
-  void launch_fused(const FusedRound& fr, double bytes) {
+  // the chained trust-region epilogue inside the fused kernel (fused_trust_phase): finite-difference models with dependency levels; its
+  // scratch -- 16 agents' squared control differences, one agent's rollout by levels -- lives in the idle ring
+  static constexpr bool kFusedTrust = kFusedRing > 0 && M::kRolloutLevels > 0;
+  bool fused_trust_fits() const {
+    if constexpr (!kFusedTrust) return false;
+    else {
+      using FL = FusedLayout<M, kFusedHelpers, kFusedRing>;
+      const size_t ring = static_cast<size_t>(kFusedRing) * 64 * FL::TS;
+      return switches.fused_trust && static_cast<size_t>(kFusedAgents) * ((d.T * NU) | 1) <= ring && LevelsLayout<M>::doubles(d.T) <= ring;
+    }
+  }
+  void launch_fused(const FusedRound& fr, double bytes, bool trust = false) {
     using FL = FusedLayout<M, kFusedHelpers, kFusedRing>;
     be.begin("linearise_riccati", bytes);
-    be.launch_kernel_lds(mas_linearise_riccati_kernel<M, kFusedHelpers, kFusedRing>, dim3(static_cast<unsigned>((d.N + kFusedAgents - 1) / kFusedAgents)),
-                         dim3(FL::kThreads), FL::kBytes, d, P, X, U, kff, Kfb, reg_events, fr);
+    const dim3 grid(static_cast<unsigned>((d.N + kFusedAgents - 1) / kFusedAgents));
+    if constexpr (kFusedTrust) {
+      if (trust) {
+        be.launch_kernel_lds(mas_linearise_riccati_kernel<M, kFusedHelpers, kFusedRing, true>, grid, dim3(FL::kThreads), FL::kBytes, d, P, X, U, kff, Kfb, reg_events, fr);
+        be.end();
+        return;
+      }
+    }
+    be.launch_kernel_lds(mas_linearise_riccati_kernel<M, kFusedHelpers, kFusedRing>, grid, dim3(FL::kThreads), FL::kBytes, d, P, X, U, kff, Kfb, reg_events, fr);
     be.end();
   }
   // Round r:  fused(r) runs select(r-1) (r > 0), commits what it accepted, linearises and walks the recursion for the agents
   // still active; forward(r) rolls out their trials and its first lane publishes the counters of select(r-1).  So the host
   // learns the outcome of round r-1 with the event of round r -- one round later than the unfused loop -- and the loop ends
   // with the round whose select found no active agent left (that round's commit has run in the same kernel).
-  void fused_rounds(int n_solves, bool timed, const ForwardBody<M>& fwd_proto) {
+  void fused_rounds(int n_solves, bool timed, const ForwardBody<M>& fwd_proto, bool trust = false) {
     const long long round_limit = static_cast<long long>(max_iterations) * n_solves;   // the last select runs in round `round_limit`
     constexpr int kRing = kCounterRing;
     struct Marks { size_t p0, p1; };
@@ -1260,7 +1280,8 @@ class SolverImpl final : public SolverBase {
       fr.do_select = r > 0 ? 1 : 0;
       fr.Xs = Xs; fr.Us = Us; fr.planes_by_slot = by_slot[(r + 1) & 1] ? 1 : 0; fr.slot_prev = slot_of[(r + 1) & 1];
       fr.error = fused_error;
-      launch_fused(fr, fused_bytes());
+      if (trust) { fr.ts = TrustState{cost, merit, cost_old, radii, trust_verdict}; fr.X_old = X_old; fr.U_old = U_old; fr.x0 = x0; fr.dt = dt; }
+      launch_fused(fr, fused_bytes(), trust);
       ForwardBody<M> fwd = fwd_proto;
       if (r > 0) { fwd.publish = Publish{ctr_prev, host_counters + 16 + (r % kRing), 2, fused_error}; fwd.publish.tag = round_tag(r); }
       const int* live = (r == 0) ? live_count0 : reinterpret_cast<const int*>(ctr_prev);

@@ -490,7 +490,8 @@ def test_sin_cos_tan_on_the_device_are_the_oracles_bits_and_within_an_ulp_of_gli
 
 @pytest.mark.parametrize("model,T,dt,strategy,outer", [("MODEL_SINGLE_TRACK", 60, 0.5, "sequential", 4), ("MODEL_SINGLE_TRACK", 40, 0.5, "trustregion", 3),
                                                        ("MODEL_SINGLE_TRACK", 40, 0.5, "centralized", 1), ("MODEL_LQR_IDENTITY", 30, 0.1, "sequential", 3),
-                                                       ("MODEL_SINGLE_TRACK_LANE", 50, 0.1, "sequential", 2), ("MODEL_BICYCLE6", 80, 0.25, "trustregion", 3)])
+                                                       ("MODEL_SINGLE_TRACK_LANE", 50, 0.1, "sequential", 2), ("MODEL_BICYCLE6", 80, 0.25, "trustregion", 3),
+                                                       ("MODEL_SINGLE_TRACK", 100, 0.5, "trustregion", 10), ("MODEL_SINGLE_TRACK_LANE", 30, 0.1, "trustregion", 4)])
 def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
     """The second half of round 2 added a second form of three kernels: line search / initial rollout / trust-region re-roll with
     four lanes per rollout (DPP quads) beside one lane per rollout, and the backward pass in registers + DPP (NX = 4) beside the
@@ -499,7 +500,9 @@ def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
     forced through mas_hip_set_option -- equal results (and both equal to the oracle).  Round 3: the default is also the two-kernel
     fused round (mas_fused_hip.hpp) for the four-state models; "fused": 0 gives the five-kernel round with the new forms.  For
     the six-state model the default at 330 agents is the LDS-tile kernel with 64 lanes per agent ("backward_wave_max": 0: 32 lanes, and
-    "backward_wide_max": 0: 16 lanes)."""
+    "backward_wide_max": 0: 16 lanes).  Round 4: the chained trust-region strategy on the four-state models also runs two-kernel rounds, its
+    epilogue (step norm, re-roll by dependency levels, accept / revert) inside the fused kernel (fused_trust_phase); "fused_trust": 0
+    gives the five-kernel round with the epilogue as a kernel of its own."""
     mid = getattr(oracle, model)
     N = 330
     rng = np.random.default_rng(7)
@@ -514,6 +517,7 @@ def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
         others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"backward_wave_max": 0}))
     if strategy == "trustregion":     # round 4: the chained epilogue as one kernel (re-roll by dependency levels) against norm / re-roll / copy kernels
         others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"trust_fused_max": 0}))
+        others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"fused_trust": 0}))
         others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"trust_fused_max": 0, "trust_reroll_levels": 0}))   # (re-roll with four lanes per rollout)
         others.append(run_batch(gpu_lib, mid, x0, None, T, dt, strategy, max_outer=outer, options={"trust_fused_max": 0, "trust_reroll_levels": 0, "fused": 0, "forward_quad_max": 0}))
         assert all(np.array_equal(new["radii"], other["radii"]) for other in others)
