@@ -22,11 +22,7 @@
 #include "mas_central.hpp"
 #include "mas_dense.hpp"
 #include "mas_rccl.hpp"
-#if !defined(MAS_HOST_EMULATION)
-#include "mas_kernels_hip.hpp"
-#include "mas_fused_hip.hpp"
-#include "mas_dense_chip.hpp"
-#endif
+#include "mas_forms.hpp"      // the kernel forms this build can launch (product: hand-written gfx950 kernels; the test-only host emulation: none)
 
 namespace mas {
 
@@ -246,38 +242,11 @@ class SolverImpl final : public SolverBase {
   // integrate_horizon + objective of every agent: four lanes per agent where the dynamics allow it (mas_rollout_quad_kernel)
   void launch_rollout_cost() {
     const RolloutCostBody<M> body{d, dt, P, x0, U, X, cost, merit, nullptr, al_view(al_enabled)};
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (M::kQuadRk4 && !kConstrained) {
-      if (quad_forward_max_slots() > 0) {
-        be.begin("rollout_cost", 0.0);
-        be.launch_kernel(mas_rollout_quad_kernel<M>, dim3(static_cast<unsigned>((static_cast<size_t>(d.N) * 4 + 255) / 256)), dim3(256), body);
-        be.end();
-        return;
-      }
-    }
-#endif
+    if (form_rollout_cost(body)) return;
     be.template launch_1d<1>("rollout_cost", body, d.N);
   }
   void launch_trust_reroll(const TrustRerollBody<M>& body) {
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (M::kRolloutLevels > 0 && !kConstrained) {      // by dependency levels, a workgroup per queued agent (mas_kernel_levels.hpp); the grid is bounded by the live count
-      using LV = LevelsLayout<M>;
-      if (switches.trust_reroll_levels && LV::bytes(d.T) <= 150 * 1024) {
-        be.begin("trust_reroll", 0.0);
-        be.launch_kernel_lds(mas_trust_reroll_levels_kernel<M>, dim3(static_cast<unsigned>(std::min<long long>(std::max<long long>(live_upper, 1), d.N))), dim3(LV::kThreads), LV::bytes(d.T), body);
-        be.end();
-        return;
-      }
-    }
-    if constexpr (M::kQuadRk4 && !kConstrained) {
-      if (quad_forward_max_slots() > 0) {
-        be.begin("trust_reroll", 0.0);
-        be.launch_kernel(mas_trust_reroll_quad_kernel<M>, dim3(static_cast<unsigned>((static_cast<size_t>(d.N) * 4 + 255) / 256)), dim3(256), body);
-        be.end();
-        return;
-      }
-    }
-#endif
+    if (form_trust_reroll(body)) return;
     be.template launch_1d<1>("trust_reroll", body, d.N);
   }
   void initialize_problem() override {
@@ -472,11 +441,7 @@ class SolverImpl final : public SolverBase {
     // the host runs one iteration AHEAD of the device: iteration r+1 is enqueued before the read-back of r is awaited; if r
     // turns out to have ended the solve, the kernels enqueued behind it find no active agent (CentralSelectBody::active).
     // A finite max_ms is checked at the top of every iteration (ilqr.hpp:84-90) and keeps the loop in step with the device.
-#if defined(MAS_HOST_EMULATION)
-    const bool run_ahead = false;
-#else
-    const bool run_ahead = std::isinf(max_ms) && max_ms > 0 && !debug;
-#endif
+    const bool run_ahead = kHostRunsAhead && std::isinf(max_ms) && max_ms > 0 && !debug;
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
     int enq = 0;
@@ -549,9 +514,7 @@ class SolverImpl final : public SolverBase {
   void run_centralized_dense() override {
     Timer tm(*this);
     require(have_x0, "initial states not set");
-#if !defined(MAS_HOST_EMULATION)
-    if (switches.dense_chip) { run_centralized_dense_chip(); return; }
-#endif
+    if (form_centralized_dense()) return;      // chip-wide launches (mas_dense_chip.hpp); below: the one-workgroup form
     if (d.N > kDenseMaxAgents) throw std::invalid_argument("the literal stacked solve is limited to " + std::to_string(kDenseMaxAgents) +
                                                           " agents (4 (N nx)^2 evaluations of the N-agent cost per time step); use run_centralized");
     be.zero(U, sizeof(double) * d.T * NU * d.Np);       // the stacked OCP starts from zero controls (multi_agent_problem.hpp:124, ocp.hpp:106-109)
@@ -573,123 +536,6 @@ class SolverImpl final : public SolverBase {
     initialized = false; rollout_consistent = false;     // cost[] now holds per-agent objectives of the stacked solution, merit[] is stale
   }
 
-#if !defined(MAS_HOST_EMULATION)
-  // The same literal solve as a sequence of chip-wide launches (mas_dense_chip.hpp): ~17 launches per time step of the backward pass,
-  // every decision (rung of the ladder, step size, termination) taken on the device; the host reads one pinned word per iteration.
-  void run_centralized_dense_chip() {
-    const int N = d.N, T = d.T, n = N * NX, m = N * NU;
-    if (N > kDenseChipMaxAgents || m > kDenseChipMaxM)
-      throw std::invalid_argument("the literal stacked solve is limited to " + std::to_string(kDenseChipMaxAgents) + " agents and " + std::to_string(kDenseChipMaxM) + " stacked controls");
-    using TB = DenseTables<NX, NU>;
-    const size_t n2 = static_cast<size_t>(n) * n, m2 = static_cast<size_t>(m) * m, mn = static_cast<size_t>(m) * n;
-    const size_t nXg = static_cast<size_t>(T + 1) * n, nUg = static_cast<size_t>(T) * m;
-    if (!chip_ready) {
-      DenseChipWs& w = chip;
-      w.S = static_cast<DenseChipState*>(raw_alloc(sizeof(DenseChipState)));
-      w.Xg = dalloc(nXg); w.Ug = dalloc(nUg); w.Xt = dalloc(kNumAlphas * nXg); w.Ut = dalloc(kNumAlphas * nUg);
-      w.Ab = dalloc(static_cast<size_t>(N) * NX * NX); w.Bb = dalloc(static_cast<size_t>(N) * NX * NU);
-      w.c = dalloc(N); w.pre = dalloc(N + 1); w.cx5 = dalloc(static_cast<size_t>(N) * NX * 2); w.cx6 = dalloc(static_cast<size_t>(N) * NX * 2);
-      w.cu5 = dalloc(static_cast<size_t>(N) * NU * 2); w.cu6 = dalloc(static_cast<size_t>(N) * NU * 2);
-      w.lx = dalloc(n); w.lu = dalloc(m); w.lxx = dalloc(n2); w.luu = dalloc(m2); w.lux = dalloc(mn);
-      w.k = dalloc(nUg); w.K = dalloc(static_cast<size_t>(T) * mn);
-      w.V = dalloc(n2); w.vx = dalloc(n); w.qx = dalloc(n); w.qu = dalloc(m); w.qxx = dalloc(n2); w.qux = dalloc(mn); w.quu = dalloc(m2);
-      w.Rr = dalloc(kDenseChipRungs * m2); w.Lt = dalloc(kDenseChipRungs * m2); w.inv = dalloc(m2);
-      w.tmp_xx = dalloc(n2); w.tmp_ux = dalloc(mn); w.V3 = dalloc(n2); w.KtQuu = dalloc(mn); w.gs = dalloc(static_cast<size_t>(kNumAlphas) * (T + 1));
-      chip_bounds = dalloc(2 * NU);
-      w.host_word = static_cast<long long*>(be.alloc_pinned(sizeof(long long)));
-      hipDeviceProp_t prop;
-      MAS_HIP_CHECK(hipGetDeviceProperties(&prop, be.device));
-      chip_cus = prop.multiProcessorCount;
-      chip_ready = true;
-    }
-    DenseChipWs w = chip;
-    { double hb[2 * NU]; for (int i = 0; i < NU; ++i) { hb[i] = lb[i]; hb[NU + i] = ub[i]; } be.h2d(chip_bounds, hb, sizeof(hb)); }
-    be.zero(U, sizeof(double) * T * NU * d.Np);          // (overwritten by the hand-back; the stacked OCP starts from zero controls)
-    auto grid_for = [&](long long items, int block) { return dim3(static_cast<unsigned>(std::max<long long>(1, std::min<long long>((items + block - 1) / block, static_cast<long long>(chip_cus) * 8)))); };
-    auto launch = [&](const char* name, auto kernel, dim3 grid, dim3 block, size_t lds, auto... args) {
-      be.begin(name, 0.0);
-      be.launch_kernel_lds(kernel, grid, block, lds, args...);
-      be.end();
-    };
-    constexpr int kItems = 1 + 4 * NX + 4 * NU + NX + NU;
-    const size_t tb_bytes = TB::doubles(N) * sizeof(double);
-    int solve_cols = 32;                                  // identity columns per workgroup of LLT::solve: their vectors must fit the LDS
-    while (solve_cols > 1 && 2 * static_cast<size_t>(m) * (solve_cols + 1) * sizeof(double) > 150 * 1024) solve_cols /= 2;
-    while (solve_cols > 4 && (m + solve_cols - 1) / solve_cols < chip_cus / 8) solve_cols /= 2;     // (few columns per workgroup: the backward substitution is one lane per column)
-    const size_t solve_bytes = 2 * static_cast<size_t>(m) * (solve_cols + 1) * sizeof(double);     // the columns' vectors + the products of the backward substitution
-    auto stage_sums = [&](const double* Xs, const double* Us, int planes, bool ignore_stop) {
-      launch("dense_objective", dc_stage_sums<M>, grid_for(static_cast<long long>(planes) * (T + 1), 64), dim3(64), 0, w, d, P, Xs, Us, planes, ignore_stop);
-    };
-    auto linearise = [&](long long fd_items) {            // tables -> prefix -> every finite difference of the summed cost at S->t
-      launch("dense_tables", dc_tables<M>, grid_for(static_cast<long long>(N) * kItems, 64), dim3(64), 0, w, d, P);
-      launch("dense_prefix", dc_prefix, dim3(1), dim3(64), 0, w, N);
-      launch("dense_fd", dc_fd<M>, grid_for(fd_items, 256), dim3(256), tb_bytes, w, d, P);
-    };
-    auto symmetrise = [&]() {
-      launch("dense_symmetrise", dc_symmetrise, grid_for(static_cast<long long>(n2), 256), dim3(256), 0, w, n, 0);
-      launch("dense_symmetrise", dc_symmetrise, grid_for(static_cast<long long>(n2), 256), dim3(256), 0, w, n, 1);
-      launch("dense_step_end", dc_step_end, dim3(1), dim3(64), 0, w, T);
-    };
-    auto gemm_tiles = [&](int mm, int nn) { return dim3(static_cast<unsigned>(std::max(1, ((mm + 63) / 64) * ((nn + 63) / 64)))); };
-
-    *w.host_word = 0;
-    launch("dense_init", dc_init<M>, grid_for(static_cast<long long>(nUg) + n, 256), dim3(256), 0, w, d, static_cast<const double*>(x0));
-    launch("dense_rollout", dc_rollout<M>, grid_for(N, 64), dim3(64), 0, w, d, dt, P);
-    stage_sums(w.Xg, w.Ug, 1, true);
-    launch("dense_merit", dc_initial_merit, dim3(1), dim3(64), 0, w, T);
-    int iterations = 0; bool done = false;
-    for (int iter = 0; iter < max_iterations && !done; ++iter) {
-      launch("dense_begin", dc_begin_iteration, dim3(1), dim3(64), 0, w, T, iter, max_ms);
-      linearise(static_cast<long long>(n) + static_cast<long long>(n2));                              // terminal boundary (ilqr.hpp:92-102)
-      symmetrise();
-      for (int t = T - 1; t >= 0; --t) {
-        linearise(static_cast<long long>(n) + m + static_cast<long long>(n2) + static_cast<long long>(m2) + static_cast<long long>(mn));
-        launch("dense_assemble", dc_assemble1<NX, NU>, grid_for(static_cast<long long>(n) + m + n2 + mn, 256), dim3(256), 0, w, N);
-        launch("dense_assemble", dc_assemble2<NX, NU>, grid_for(static_cast<long long>(n2) + mn + m2, 256), dim3(256), 0, w, N);
-        launch("dense_ladder", dc_ladder, dim3(kDenseChipRungs), dim3(m <= 64 ? 64 : m <= 128 ? 128 : m <= 256 ? 256 : 512), static_cast<size_t>(kDcPanel) * m * sizeof(double), w, m);
-        launch("dense_solve", dc_solve, dim3(static_cast<unsigned>((m + solve_cols - 1) / solve_cols)), dim3(m <= 64 ? 64 : m <= 128 ? 128 : m <= 256 ? 256 : 512), solve_bytes, w, m, solve_cols);
-        launch("dense_gain", dc_gain_k, grid_for(m, 64), dim3(64), 0, w, m);
-        double* Kt = w.K + static_cast<size_t>(t) * mn;
-        launch("dense_gemm", dc_gemm<false, true>, gemm_tiles(m, n), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(w.inv), static_cast<const double*>(w.qux), Kt, m, m, n);   // K = -Quu^-1 q_ux
-        launch("dense_gemm", dc_gemm<true, false>, gemm_tiles(n, m), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(Kt), static_cast<const double*>(w.quu), w.KtQuu, n, m, m);  // K^T q_uu
-        launch("dense_vx", dc_vx, grid_for(n, 64), dim3(64), 0, w, n, m);
-        launch("dense_gemm", dc_gemm<true, false>, gemm_tiles(n, n), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(Kt), static_cast<const double*>(w.qux), w.tmp_xx, n, m, n); // K^T q_ux
-        launch("dense_gemm", dc_gemm<false, false>, gemm_tiles(n, n), dim3(256), 0, static_cast<const DenseChipState*>(w.S), static_cast<const double*>(w.KtQuu), static_cast<const double*>(Kt), w.V3, n, m, n);  // (K^T q_uu) K
-        launch("dense_vxx", dc_vxx, grid_for(static_cast<long long>(n2), 256), dim3(256), 0, w, n);
-        symmetrise();
-      }
-      launch("dense_trials", dc_trials<M>, dim3(kNumAlphas), dim3(512), static_cast<size_t>(2 * n + m) * sizeof(double), w, d, dt, P, clamp,
-             static_cast<const double*>(chip_bounds), static_cast<const double*>(chip_bounds + NU));
-      stage_sums(w.Xt, w.Ut, kNumAlphas, false);
-      launch("dense_accept", dc_accept, dim3(1), dim3(64), 0, w, T, tolerance, max_iterations);
-      launch("dense_commit", dc_commit, grid_for(static_cast<long long>(nXg + nUg), 256), dim3(256), 0, w, T, n, m);
-      // one pinned word per iteration: (iterations << 8) | stop
-      volatile long long* word = w.host_word;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (long long spins = 1;; ++spins) {
-        const long long v = *word;
-        if ((v >> 8) >= iter + 1 || (v & 1)) { iterations = static_cast<int>(v >> 8); done = (v & 1) != 0; break; }
-        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) {
-          try { be.sync(); } catch (...) {}
-          throw std::runtime_error("the literal stacked solve did not finish an iteration within 600 s");
-        }
-      }
-    }
-    launch("dense_handback", dc_handback<M>, grid_for(N, 64), dim3(64), 0, w, d, P, X, U, cost, iters_total, exit_code, reg_events, central);
-    be.d2h(&host_central[0].st, central, sizeof(CentralState));
-    const CentralState& hc = host_central[0].st;
-    central_total = hc.cur_total; last_total_valid = true;
-    stats.solves += 1; stats.agent_iterations += static_cast<long long>(hc.iterations) * d.N; stats.batch_iterations += hc.iterations;
-    if (hc.done) stats.converged_solves += 1;
-    controls_zero = false;
-    initialized = false; rollout_consistent = false;
-    (void)iterations;
-  }
-  DenseChipWs chip{}; bool chip_ready = false; int chip_cus = 256; double* chip_bounds = nullptr;
-  void free_chip_word() { if (chip.host_word) be.free_pinned(chip.host_word); chip.host_word = nullptr; }
-#else
-  void free_chip_word() {}
-#endif
 
   void get_solution(double* Xo, double* Uo, double* co, int32_t* it, int32_t* ex, bool device_ptr) override {
     if (device_ptr) {                  // the layout conversion writes the caller's device buffers directly
@@ -712,19 +558,7 @@ class SolverImpl final : public SolverBase {
     be.template launch_1d<1>("begin_solve", BeginSolveBody{active, iters_solve, exit_code, alpha_sel}, d.N);
     { std::vector<long long> rg(d.N); be.d2h(rg.data(), reg_events, sizeof(long long) * d.N); for (auto v : rg) reg_base += v; }   // keep the running statistics
     be.zero(reg_events, sizeof(long long) * d.Np);
-    bool staged_fused = false;
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (kFusable) {
-      if (fused_enabled() && kFusedRing > 0) {            // the product's form of sweep + backward: the fused kernel, its tiles also dumped to the tile array
-                                                             // (all-analytic models form no tiles in the fused kernel: their staged access stays with the sweep kernel)
-        FusedRound fr;
-        fr.sel = SelectBody{}; fr.sel.active = active; fr.sel.alpha_sel = alpha_sel;
-        fr.do_select = 0; fr.Xs = Xs; fr.Us = Us; fr.slot_prev = slot_of[0]; fr.D_dump = D; fr.error = fused_error;
-        launch_fused(fr, 0.0);
-        staged_fused = true;
-      }
-    }
-#endif
+    const bool staged_fused = form_staged_backward();
     if (!staged_fused) {
       launch_sweep(0.0);
       launch_backward(0.0);
@@ -744,29 +578,7 @@ class SolverImpl final : public SolverBase {
     return s;
   }
   // in-kernel timing of the sweep -> kernel statistics entry "sweep_inkernel" (100-MHz REFCLK ticks)
-  void fold_kernel_stamps() override {
-#if !defined(MAS_HOST_EMULATION)
-    if (!sweep_stamps || stamp_launches.empty()) return;
-    be.sync();
-    std::vector<unsigned long long> h(stamp_used);
-    be.d2h(h.data(), sweep_stamps, sizeof(unsigned long long) * stamp_used);
-    KernelStat& ks = be.stats["sweep_inkernel"];
-    for (const auto& sl : stamp_launches) {
-      unsigned long long lo_t = ~0ull, hi_t = 0ull;
-      for (size_t b = 0; b < sl.count; b += 2) {
-        if (h[sl.off + b] == 0ull) continue;                       // workgroup never ran (cannot happen) or slot unused
-        lo_t = std::min(lo_t, h[sl.off + b]); hi_t = std::max(hi_t, h[sl.off + b + 1]);
-      }
-      if (hi_t == 0ull) continue;
-      ks.launches++; ks.total_ms += static_cast<double>(hi_t - lo_t) * 1e-5; ks.algorithmic_bytes += sl.bytes;
-      if (sl.bytes >= sweep_bytes() * static_cast<double>(d.N)) {   // launches with every agent active: the kernel at its design point
-        KernelStat& kf = be.stats["sweep_inkernel_full"];
-        kf.launches++; kf.total_ms += static_cast<double>(hi_t - lo_t) * 1e-5; kf.algorithmic_bytes += sl.bytes;
-      }
-    }
-    stamp_used = 0; stamp_launches.clear();
-#endif
-  }
+  void fold_kernel_stamps() override { form_fold_kernel_stamps(); }
   void reset_stats() override {
     stats = HostStats{}; reg_base = 0; stamp_used = 0; stamp_launches.clear();
     be.zero(reg_events, sizeof(long long) * d.Np);
@@ -814,31 +626,8 @@ class SolverImpl final : public SolverBase {
   void launch_sweep(double bytes) { launch_sweep(bytes, 0, d.N); }
   // slots: with a live list, an upper bound of its length (the grid covers that many list slots)
   void launch_sweep(double bytes, int lo, int hi, const int* live_count = nullptr, int slots = 0, const int* live_list = nullptr) {
-    (void)live_count; (void)slots; (void)live_list;
-#if defined(MAS_HOST_EMULATION)
+    if (form_sweep(bytes, lo, hi, live_count, slots, live_list)) return;
     be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
-#else
-    if constexpr (kConstrained) {     // constrained test workloads: plain body (tile = ND doubles incl. constraint Jacobians)
-      be.template launch_2d_range<4>("sweep", SweepBody<M>{d, P, X, U, D, active}, lo, hi, d.T, bytes);
-      return;
-    }
-    be.begin("sweep", bytes);
-    unsigned long long* stamp = nullptr;
-    const dim3 grid(((live_count ? slots : hi - lo) + 63) / 64, (d.T + 3) / 4);
-    if (be.profiling) {                                   // in-kernel REFCLK stamps for the roofline kernel
-      const size_t per_launch = 2 * static_cast<size_t>(grid.x) * grid.y;
-      if (!sweep_stamps) { stamp_capacity = per_launch * kMaxStampedLaunches; sweep_stamps = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * stamp_capacity)); }
-      if (stamp_used + per_launch <= stamp_capacity) {
-        stamp = sweep_stamps + stamp_used;
-        MAS_HIP_CHECK(hipMemsetAsync(stamp, 0, sizeof(unsigned long long) * per_launch, be.cur));
-        stamp_launches.push_back({stamp_used, per_launch, bytes});
-        stamp_used += per_launch;
-      }
-    }
-    be.launch_kernel(mas_sweep_kernel<M>, grid, dim3(64, 4), d, P, X, U, D, active, lo, hi, stamp,
-                     static_cast<const int*>(live_count ? live_list : nullptr), live_count);
-    be.end();
-#endif
   }
   // line-search rollouts.  Returns true when the trial planes were written slot-indexed (mas_forward_quad_kernel), i.e. the
   // commit has to map slots back to agents.  One lane per rollout (ForwardBody) while the rollouts fill the chip; four lanes
@@ -846,17 +635,7 @@ class SolverImpl final : public SolverBase {
   // where the launch time is one wavefront's chain and the quad form makes that chain ~40 % shorter.
   // live_count: device-side length of live_list (null: every agent, slot == agent); slots: host-side upper bound of it
   bool launch_forward(const ForwardBody<M>& fwd, double bytes, const int* live_list, const int* live_count, long long slots) {
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (M::kQuadRk4 && !kConstrained) {
-      if (slots <= quad_forward_max_slots()) {
-        be.begin("forward", bytes);
-        be.launch_kernel(mas_forward_quad_kernel<M>, dim3(static_cast<unsigned>((slots + 63) / 64), kNumAlphas), dim3(256), fwd, live_list, live_count);
-        be.end();
-        return true;
-      }
-    }
-#endif
-    (void)live_list; (void)live_count; (void)slots;
+    if (form_forward_by_slot(fwd, bytes, live_list, live_count, slots)) return true;
     be.template launch_2d_range<kForwardTrialsPerBlock>("forward", fwd, 0, d.N, kNumAlphas, bytes);
     return false;
   }
@@ -867,57 +646,11 @@ class SolverImpl final : public SolverBase {
   }
   // chained trust-region epilogue as one kernel (mas_trust_epilogue_kernel): vehicle models, rounds with at most trust_fused_max live
   // agents (the grid is bounded by the live count: at most that many solves can have ended).  false: the three-kernel form runs.
-  bool launch_trust_epilogue(const int* ended_count) {
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (M::kRolloutLevels > 0 && !kConstrained) {
-      using LV = LevelsLayout<M>;
-      if (live_upper <= switches.trust_fused_max && LV::bytes(d.T) <= 150 * 1024) {
-        const TrustState ts{cost, merit, cost_old, radii, trust_verdict};
-        be.begin("trust_epilogue", 0.0);
-        be.launch_kernel_lds(mas_trust_epilogue_kernel<M>, dim3(static_cast<unsigned>(std::min<long long>(live_upper, d.N))), dim3(LV::kThreads), LV::bytes(d.T),
-                             d, dt, P, static_cast<const double*>(x0), X, U, X_old, U_old, ts, static_cast<const int*>(trust_ended_list), ended_count);
-        be.end();
-        return true;
-      }
-    }
-#endif
-    (void)ended_count;
-    return false;
-  }
+  bool launch_trust_epilogue(const int* ended_count) { return form_trust_epilogue(ended_count); }
   // backward pass of the stacked problem: the 16-lane tile kernel with the rung agreement across all wavefronts
   // (LadderSync); constrained models and the host emulation keep the one-workgroup body
   void launch_central_backward(double bytes) {
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (!kConstrained) {
-      if (ladder_resident()) {
-      const size_t words = static_cast<size_t>(d.T) * LadderSync::kChunks * 4;
-      if (!ladder_sync) ladder_sync = static_cast<unsigned long long*>(raw_alloc(sizeof(unsigned long long) * (words + 2)));
-      MAS_HIP_CHECK(hipMemsetAsync(ladder_sync, 0, sizeof(unsigned long long) * (words + 2), be.cur));
-      LadderSync sy{ladder_sync, reinterpret_cast<int*>(ladder_sync + words)};
-      sy.combine = switches.central_combine; sy.peek = switches.central_peek;
-      constexpr int apw = 64 / kLanes;
-      be.begin("central_backward", bytes);
-      const int wpb = central_waves_per_block();
-      auto launch = [&](auto kernel, int w) {
-        const int agents_per_block = apw * w;
-        const int groups = (d.N + agents_per_block - 1) / agents_per_block;
-        // up to 32 working workgroups (one per CU of an XCD) are placed on ONE XCD by launching eight times as many and letting
-        // every eighth work (LadderSync::xcd_stride); only the pipelined kernel knows the stride
-        // (a CU takes one wavefront per SIMD of this kernel: 32 CUs of an XCD hold 32 four-wavefront workgroups or 128 single-wavefront ones)
-        sy.xcd_stride = (central_pipelined() && groups > 1 && groups <= 32 * std::max(1, 4 / w) && central_one_xcd() && ladder_one_xcd_ok) ? 8 : 1;
-        be.launch_kernel(kernel, dim3(groups * sy.xcd_stride), dim3(64 * w), d, P, X, D, kff, Kfb,
-                         reg_events, active, 0, static_cast<int>(d.N), sy);
-      };
-      if (wpb == 16) launch(central_kernel<16>(), 16);
-      else if (wpb == 8) launch(central_kernel<8>(), 8);
-      else if (wpb == 4) launch(central_kernel<4>(), 4);
-      else if (wpb == 2) launch(central_kernel<2>(), 2);
-      else launch(central_kernel<1>(), 1);
-      be.end();
-      return;
-      }
-    }
-#endif
+    if (form_central_backward(bytes)) return;
     if (!Dsoa) Dsoa = dalloc(static_cast<size_t>(d.T) * L::ND * d.Np);
     be.template launch_2d<4>("tiles_to_soa", TilesToSoaBody{d, L::ND, D, Dsoa}, d.N, d.T);
     be.launch_group("central_backward", CentralBackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, Dsoa, active}, d.N, bytes);
@@ -927,105 +660,10 @@ class SolverImpl final : public SolverBase {
   // live_list / live_count / slots: the round's compacted list of live agents, its device-side length and a host-side upper bound
   // of it (LDS-tile kernel only: LadderSync::live_list); null = agents lo .. hi-1 by their flags
   void launch_backward(double bytes, int lo, int hi, const int* live_list = nullptr, const int* live_count = nullptr, long long slots = 0) {
-    (void)live_list; (void)live_count; (void)slots;
-#if defined(MAS_HOST_EMULATION)
+    if (form_backward(bytes, lo, hi, live_list, live_count, slots)) return;
     be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active, al_view(al_enabled)}, lo, hi, bytes);
-#else
-    if constexpr (kConstrained) {     // the 16-lane tile kernel covers the unconstrained recursion only
-      be.template launch_1d_range<1>("backward", BackwardBody<M>{d, P, X, D, kff, Kfb, reg_events, active, al_view(al_enabled)}, lo, hi, bytes);
-      return;
-    }
-    be.begin("backward", bytes);
-    constexpr int apw = 64 / kLanes;
-    constexpr int wpb = kBackwardWavesPerBlock;       // four wavefronts per workgroup: one per SIMD of a CU (mas_kernels_hip.hpp)
-    const dim3 grid((hi - lo + wpb * apw - 1) / (wpb * apw));
-    if constexpr (NX == 4 && kLanes == 16) {     // registers + DPP form (no LDS for V and the tiles)
-      if (!backward_tile_forced()) {
-        be.launch_kernel(mas_backward_row_kernel<M, false, wpb>, grid, dim3(64 * wpb), d, P, X, D, kff, Kfb, reg_events, active, lo, hi, LadderSync{});
-        be.end();
-        return;
-      }
-    }
-    LadderSync extras{};
-    const bool listed = live_list != nullptr && backward_list_enabled();
-    if (listed) { extras.live_list = live_list; extras.live_count = live_count; }
-    const long long agents = listed ? slots : hi - lo;
-    // Tail rounds of a solve (few live agents: the launch is as long as ONE wavefront's chain of instructions): 32 lanes per agent,
-    // half the dot products per lane.  While the agents fill the chip the 16-lane form does the same work with half the wavefronts.
-    if constexpr (NX > 4 && kLanes == 16) {
-      if (agents <= switches.backward_wave_max) {
-        be.launch_kernel(mas_backward_tile_kernel<M, 64, false, wpb>, dim3(static_cast<unsigned>((agents + wpb - 1) / wpb)), dim3(64 * wpb),
-                         d, P, X, D, kff, Kfb, reg_events, active, lo, hi, extras);
-        be.end();
-        return;
-      }
-      if (agents <= switches.backward_wide_max) {
-        constexpr int apw_wide = 2;
-        be.launch_kernel(mas_backward_tile_kernel<M, 32, false, wpb>, dim3(static_cast<unsigned>((agents + wpb * apw_wide - 1) / (wpb * apw_wide))), dim3(64 * wpb),
-                         d, P, X, D, kff, Kfb, reg_events, active, lo, hi, extras);
-        be.end();
-        return;
-      }
-    }
-    const dim3 tile_grid(static_cast<unsigned>((agents + wpb * apw - 1) / (wpb * apw)));
-    be.launch_kernel(mas_backward_tile_kernel<M, kLanes, false, wpb>, tile_grid, dim3(64 * wpb), d, P, X, D, kff, Kfb,
-                     reg_events, active, lo, hi, extras);
-    be.end();
-#endif
   }
 
-#if !defined(MAS_HOST_EMULATION)
-  // the backward kernel with the shared ladder, W wavefronts per workgroup: the registers + DPP form for NX == 4, else the LDS-tile form
-  using BackwardKernelFn = void (*)(Dims, ModelParams, const double*, const double*, double*, double*, long long*, const int*, int, int, LadderSync);
-  template <int W>
-  BackwardKernelFn central_kernel() const {
-    if constexpr (NX == 4 && kLanes == 16) {
-      if (!backward_tile_forced()) {
-        if (!central_pipelined()) return mas_backward_row_kernel<M, true, W>;
-        return mas_backward_row_pipelined_kernel<M, W>;
-      }
-    }
-    return mas_backward_tile_kernel<M, kLanes, true, W>;
-  }
-  bool central_pipelined() const {                                     // false = the plain registers + DPP kernel with the shared ladder
-    if constexpr (!(NX == 4 && kLanes == 16)) return false;
-    return !backward_tile_forced() && switches.central_pipeline;
-  }
-  bool backward_list_enabled() const { return switches.backward_list; }
-  bool central_one_xcd() const { return switches.central_one_xcd; }
-  bool backward_tile_forced() const { return switches.backward_tile; }
-  void on_option_changed() override { ladder_resident_checked = false; }
-  // The rung agreement (LadderSync) is a spin barrier between the workgroups of an ordinary launch: it needs every one of
-  // them resident at once.  Checked against the occupancy the runtime reports for this kernel on this device (a
-  // partitioned device, e.g. CPX with 32 CUs, or a build with higher register use may not hold them); if they do not fit,
-  // the single-workgroup CentralBackwardBody is used instead -- slower, but it cannot starve.  Work of OTHER streams or
-  // processes on the device is outside what can be checked here: mas_hip.h states the exclusivity requirement.
-  // wavefronts per workgroup of the centralised backward pass (see mas_backward_tile_kernel): measured on C2
-  int central_waves_per_block() const {
-    return switches.central_wpb;
-  }
-  bool ladder_resident() {
-    if (ladder_resident_checked) return ladder_resident_ok;
-    ladder_resident_checked = true;
-    constexpr int apw = 64 / kLanes;
-    const int wpb = central_waves_per_block();
-    const int grid = (d.N + apw * wpb - 1) / (apw * wpb);
-    int per_cu = 0; hipDeviceProp_t prop;
-    hipError_t q = hipErrorUnknown;
-    if (wpb == 16) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<16>(), 64 * 16, 0);
-    else if (wpb == 8) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<8>(), 64 * 8, 0);
-    else if (wpb == 4) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<4>(), 64 * 4, 0);
-    else if (wpb == 2) q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<2>(), 64 * 2, 0);
-    else q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, central_kernel<1>(), 64, 0);
-    if (q != hipSuccess || hipGetDeviceProperties(&prop, be.device) != hipSuccess) { (void)hipGetLastError(); ladder_resident_ok = false; return false; }
-    ladder_resident_ok = static_cast<long long>(per_cu) * prop.multiProcessorCount >= grid;
-    // the one-XCD placement puts all working workgroups on an eighth of the CUs: it needs them resident THERE
-    ladder_one_xcd_ok = static_cast<long long>(per_cu) * (prop.multiProcessorCount / 8) >= grid;
-    if (switches.force_single_workgroup_central) ladder_resident_ok = false;   // tests: exercise the fallback
-    return ladder_resident_ok;
-  }
-  bool ladder_resident_checked = false, ladder_resident_ok = false, ladder_one_xcd_ok = false;
-#endif
 
   ALView al_view(bool on) const {
     ALView v;
@@ -1093,25 +731,13 @@ class SolverImpl final : public SolverBase {
     if (!round_events_made) { for (auto& e : round_ev) e = be.make_event(); round_events_made = true; }
     if (debug) debug_initial();
     const ForwardBody<M> fwd = make_forward();
-#if !defined(MAS_HOST_EMULATION)
-    if constexpr (kFusable) {
-      if (fused_enabled() && !debug && (!trust_epilogue || fused_trust_fits())) { fused_rounds(n_solves, timed, fwd, trust_epilogue); return; }
-    }
-#endif
-#if defined(MAS_HOST_EMULATION)
-    const bool run_ahead = false;
-#else
+    if (form_fused_rounds(n_solves, timed, fwd, trust_epilogue)) return;      // two-kernel rounds (mas_fused_hip.hpp)
     // a solve that follows a one-round solve (the re-solves of outer rounds 2..max_outer usually are) would
     // waste its run-ahead round, so run ahead only while the previous solve needed several rounds
-    const bool run_ahead = !debug && (n_solves > 1 || last_solve_rounds != 1);
-#endif
+    const bool run_ahead = kHostRunsAhead && !debug && (n_solves > 1 || last_solve_rounds != 1);
     // the host polls the round's packed word (no event between rounds: an event record costs ~6 us of device idle time per round);
     // rounds whose counters change after the commit (multiplier update) or that are inspected afterwards (debug) keep the event
-#if defined(MAS_HOST_EMULATION)
-    const bool poll = false;
-#else
-    const bool poll = !debug && !(kConstrained && al_enabled) && d.N < (1 << 24);
-#endif
+    const bool poll = kHostPolls && !debug && !(kConstrained && al_enabled) && d.N < (1 << 24);
     struct Marks { size_t p0, p1, s0, s1; };
     Marks marks[2];
     auto enqueue = [&](int r) {
@@ -1219,106 +845,6 @@ class SolverImpl final : public SolverBase {
   }
   void clear_round_words() const { volatile long long* words = host_counters + 16; for (int q = 0; q < kCounterRing; ++q) words[q] = 0; }
 
-#if !defined(MAS_HOST_EMULATION)
-  // ---- fused rounds (mas_fused_hip.hpp): round = [select of the round before + commit + linearisation || Riccati] -> line search ----
-  // helpers / ring: finite-difference models need four helper wavefronts to stay ahead of the recursion, analytic ones two
-#if defined(MAS_FUSED_HELPERS)
-  static constexpr int kFusedHelpers = MAS_FUSED_HELPERS, kFusedRing = MAS_FUSED_RING;      // (A/B builds)
-#else
-  static constexpr bool kFusedAnalytic = kAllAnalytic && NU == 4;      // no tiles at all: AnalyticSource + one committing wavefront
-  static constexpr int kFusedHelpers = kFusedAnalytic ? 1 : ((M::kAnalyticA && M::kAnalyticLxx) ? 2 : 4), kFusedRing = kFusedAnalytic ? 0 : 2;
-#endif
-  bool fused_enabled() const { return switches.fused && d.N < (1 << 24); }      // (the packed word carries 24-bit agent counts)
-  double fused_bytes() const { return sweep_bytes() + backward_bytes(); }
-  // the chained trust-region epilogue inside the fused kernel (fused_trust_phase): finite-difference models with dependency levels; its
-  // scratch -- 16 agents' squared control differences, one agent's rollout by levels -- lives in the idle ring
-  static constexpr bool kFusedTrust = kFusedRing > 0 && M::kRolloutLevels > 0;
-  bool fused_trust_fits() const {
-    if constexpr (!kFusedTrust) return false;
-    else {
-      using FL = FusedLayout<M, kFusedHelpers, kFusedRing>;
-      const size_t ring = static_cast<size_t>(kFusedRing) * 64 * FL::TS;
-      return switches.fused_trust && static_cast<size_t>(kFusedAgents) * ((d.T * NU) | 1) <= ring && LevelsLayout<M>::doubles(d.T) <= ring;
-    }
-  }
-  void launch_fused(const FusedRound& fr, double bytes, bool trust = false) {
-    using FL = FusedLayout<M, kFusedHelpers, kFusedRing>;
-    be.begin("linearise_riccati", bytes);
-    const dim3 grid(static_cast<unsigned>((d.N + kFusedAgents - 1) / kFusedAgents));
-    if constexpr (kFusedTrust) {
-      if (trust) {
-        be.launch_kernel_lds(mas_linearise_riccati_kernel<M, kFusedHelpers, kFusedRing, true>, grid, dim3(FL::kThreads), FL::kBytes, d, P, X, U, kff, Kfb, reg_events, fr);
-        be.end();
-        return;
-      }
-    }
-    be.launch_kernel_lds(mas_linearise_riccati_kernel<M, kFusedHelpers, kFusedRing>, grid, dim3(FL::kThreads), FL::kBytes, d, P, X, U, kff, Kfb, reg_events, fr);
-    be.end();
-  }
-  // Round r:  fused(r) runs select(r-1) (r > 0), commits what it accepted, linearises and walks the recursion for the agents
-  // still active; forward(r) rolls out their trials and its first lane publishes the counters of select(r-1).  So the host
-  // learns the outcome of round r-1 with the event of round r -- one round later than the unfused loop -- and the loop ends
-  // with the round whose select found no active agent left (that round's commit has run in the same kernel).
-  void fused_rounds(int n_solves, bool timed, const ForwardBody<M>& fwd_proto, bool trust = false) {
-    const long long round_limit = static_cast<long long>(max_iterations) * n_solves;   // the last select runs in round `round_limit`
-    constexpr int kRing = kCounterRing;
-    struct Marks { size_t p0, p1; };
-    Marks marks[2];
-    bool by_slot[2] = {false, false};
-    be.zero(fused_error, sizeof(int));
-    clear_round_words();                                                // pinned words 16 .. 16 + kRing - 1: one packed word per round (Publish::pack); the device writes nothing here before round 1 of this call
-    auto enqueue = [&](long long r) {
-      Marks& mk = marks[r & 1];
-      mk.p0 = be.mark();
-      FusedRound fr;
-      long long* ctr_prev = counters + 2 * ((r + kRing - 1) % kRing);            // counted by select(r-1), which runs in this round's first kernel
-      long long* ctr_clear = counters + 2 * ((r + 1) % kRing);
-      fr.sel = SelectBody{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,
-                          iters_total, exit_code, reinterpret_cast<int*>(ctr_prev), ctr_prev + 1, ctr_clear,
-                          nullptr, nullptr, live_lists[r & 1], n_solves > 1 ? solves_left : nullptr, timed ? solve_start : nullptr, max_ms,
-                          nullptr, nullptr, nullptr, slot_of[r & 1]};
-      fr.do_select = r > 0 ? 1 : 0;
-      fr.Xs = Xs; fr.Us = Us; fr.planes_by_slot = by_slot[(r + 1) & 1] ? 1 : 0; fr.slot_prev = slot_of[(r + 1) & 1];
-      fr.error = fused_error;
-      if (trust) { fr.ts = TrustState{cost, merit, cost_old, radii, trust_verdict}; fr.X_old = X_old; fr.U_old = U_old; fr.x0 = x0; fr.dt = dt; }
-      launch_fused(fr, fused_bytes(), trust);
-      ForwardBody<M> fwd = fwd_proto;
-      if (r > 0) { fwd.publish = Publish{ctr_prev, host_counters + 16 + (r % kRing), 2, fused_error}; fwd.publish.tag = round_tag(r); }
-      const int* live = (r == 0) ? live_count0 : reinterpret_cast<const int*>(ctr_prev);
-      by_slot[r & 1] = launch_forward(fwd, forward_bytes() * kNumAlphas, live_lists[r & 1], live, live_upper);
-      mk.p1 = be.mark();
-    };
-    // The first lane of forward(r) publishes the outcome of select(r-1) in ONE 64-bit store to pinned memory and the host polls
-    // that word: no event between the kernels of consecutive rounds (an event record costs ~6 us of gap per round), and the host
-    // knows a whole line search ahead whether round r+1 is needed -- it is, exactly when round r still had active agents -- so
-    // nothing is enqueued speculatively and the loop ends with the round that only selects and commits.
-    long long n_before = d.N;             // agents active at the start of the round whose outcome is read next
-    live_upper = d.N;
-    int rounds_this_solve = 0; bool gave_up = false;
-    if (max_iterations > 0 && !(timed && 0.0 > max_ms)) {
-      enqueue(0);
-      enqueue(1);                         // select(0) + commit: always needed
-      be.scale_bytes(marks[0].p0, marks[0].p1, static_cast<double>(d.N));
-      for (long long r = 1;; ++r) {       // rounds 0 .. r are enqueued
-        const long long w = await_round_word(r);
-        const long long n_after = w & Publish::kMask24, conv = (w >> Publish::kConvShift) & Publish::kMask24;
-        if ((w >> Publish::kFlagShift) & 1) { gave_up = true; break; }
-        stats.agent_iterations += n_before;           // round r-1 ran one iLQR iteration on every agent active at its start
-        stats.converged_solves += conv;
-        stats.batch_iterations++; ++rounds_this_solve;
-        be.scale_bytes(marks[r & 1].p0, marks[r & 1].p1, static_cast<double>(n_after));
-        n_before = n_after;
-        live_upper = std::max<long long>(n_after, 1);
-        if (n_after == 0 || r + 1 > round_limit) break;
-        enqueue(r + 1);
-      }
-    } else if (max_iterations > 0) {
-      be.template launch_1d<1>("mark_timeout", MarkTimeoutBody{active, exit_code}, d.N);
-    }
-    last_solve_rounds = rounds_this_solve;
-    if (gave_up) { be.sync(); throw std::runtime_error("fused round: a bounded wait inside a workgroup gave up"); }
-  }
-#endif
 
   // "debug" key (ilqr.hpp:45,79-80,262-267): the reference prints one line per solve start and one per iteration of
   // every agent (interleaved arbitrarily across OpenMP threads); here the same lines, agent by agent after each round,
@@ -1360,14 +886,12 @@ class SolverImpl final : public SolverBase {
   void download(double* dst, size_t n, bool device_ptr) { if (device_ptr) { be.d2d(dst, stage, sizeof(double) * n); be.sync(); } else be.d2h(dst, stage, sizeof(double) * n); }
   void* raw_alloc(size_t bytes) { void* p = be.alloc(bytes); allocations.push_back(p); return p; }   // freed by the destructor
   // device address of the "gave up waiting" flag of the rung agreement (null while the single-workgroup fallback is in use)
-  const int* ladder_error_flag() const {
-#if !defined(MAS_HOST_EMULATION)
-    if (ladder_sync) return reinterpret_cast<const int*>(ladder_sync + static_cast<size_t>(d.T) * LadderSync::kChunks * 4);
-#endif
-    return nullptr;
-  }
+  const int* ladder_error_flag() const { return form_ladder_error_flag(); }
   double* dalloc(size_t n) { void* p = be.alloc(sizeof(double) * n); allocations.push_back(p); return static_cast<double*>(p); }
   int* ialloc(size_t n) { void* p = be.alloc(sizeof(int) * n); allocations.push_back(p); return static_cast<int*>(p); }
+
+  // ---- the kernel forms of this build: form_*() launches a specialised kernel and returns true, or returns false and the generic body above runs
+#include MAS_SOLVER_FORMS
 
   Dims d{}; double dt = 0.0; ModelParams P{}; bool clamp = false; double lb[NU], ub[NU];
   double *x0 = nullptr, *X = nullptr, *U = nullptr, *D = nullptr, *kff = nullptr, *Kfb = nullptr, *Xs = nullptr, *Us = nullptr;

@@ -1,4 +1,4 @@
-"""Hash of the sources libmas_hip.so is built from (csrc/*.hpp, csrc/*.hip, include/*.h).
+"""Hash of the sources libmas_hip.so is built from (csrc/*.hpp, csrc/*.inc, csrc/*.hip, include/*.h).
 
 tools/collect_profiles.sh stamps it into every profiles/*.json it writes; bench.py recomputes it and refuses to quote counter data
 (HBM traffic, SQ utilisation) collected from other sources -- a stale profile shows up as `null` with the reason, not as a number."""
@@ -13,7 +13,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def source_files():
     csrc = os.path.join(_ROOT, "multi_agent_solver_amd", "csrc")
     inc = os.path.join(_ROOT, "include")
-    return ([os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hpp", ".hip"))] +
+    return ([os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hpp", ".hip", ".inc"))] +
             [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")])
 
 

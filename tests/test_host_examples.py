@@ -80,7 +80,8 @@ def test_single_track_example_matches_oracle(exe_dir, oracle, strategy):
 
 @pytest.mark.gpu
 def test_centralized_example_switches_reading_with_the_agent_count(exe_dir, oracle):
-    """reference default (10 agents, T = 10): the literal stacked solve; beyond 16 agents: the block-diagonal reading"""
+    """reference default (10 agents, T = 10) and everything up to 64 agents: the literal stacked solve (chip-wide launches since round 4);
+    beyond: the block-diagonal reading"""
     r = _run(exe_dir, "multi_agent_single_track", "--quiet")
     assert r.returncode == 0, r.stderr
     o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(10), None, 10, 0.5, strategy="centralized_dense")
@@ -90,8 +91,14 @@ def test_centralized_example_switches_reading_with_the_agent_count(exe_dir, orac
     #  the algorithm turns that into 2e-5 of the total cost.  Inputs are outside the parity claim; equal inputs give equal bits.)
     r = _run(exe_dir, "multi_agent_single_track", "--agents", "24", "--quiet")
     assert r.returncode == 0, r.stderr
-    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(24), None, 10, 0.5, strategy="centralized")
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(24), None, 10, 0.5, strategy="centralized_dense_structured")
     assert abs(float(_result_line(r.stdout).group(4)) - o["total_cost"]) <= 1e-6      # printed with six decimals
+    r = _run(exe_dir, "multi_agent_single_track", "--agents", "72", "--quiet")
+    assert r.returncode == 0, r.stderr
+    blocked = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(72), None, 10, 0.5, strategy="centralized")["total_cost"]
+    literal = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(72), None, 10, 0.5, strategy="centralized_dense_structured")["total_cost"]
+    printed = float(_result_line(r.stdout).group(4))
+    assert abs(printed - blocked) <= 1e-4 * blocked and abs(printed - blocked) < 0.1 * abs(printed - literal)      # (inputs may differ in a last bit, see above)
 
 
 @pytest.mark.gpu

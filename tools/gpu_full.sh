@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU tier + the driver's bench command (run through gpurun from the repo root)
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r4_gpu_tests.txt 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/r4_gpu_tests.txt
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/r4_gpu_tests.txt 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/r4_gpu_tests.txt
 timeout -k 10 400 python bench.py > gpurun_out/r4_bench_c3.json 2> gpurun_out/r4_bench_c3.err; echo "bench rc=$?"; tail -3 gpurun_out/r4_bench_c3.err
 python - <<'PY'
 import json
