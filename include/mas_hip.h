@@ -117,6 +117,24 @@ typedef struct mas_hip_problem_desc {
 int mas_hip_abi_version(void);
 int mas_hip_device_count(void);
 int mas_hip_model_dims(int model_id, int* nx, int* nu);
+
+/* User-defined workloads.  The reference takes a workload as std::function callbacks (types.hpp:21-50: dynamics, stage_cost,
+ * terminal_cost; every derivative hook an example leaves empty is finite-differenced, ocp.hpp:117-135); callbacks cannot run on the
+ * device, so a workload is a C++ struct of static functions that the kernel templates are instantiated with.  The built-in ones
+ * (enum mas_hip_model) are compiled into libmas_hip.so; a new one needs NO rebuild of the library:
+ *   struct_source   the definition of one struct deriving from mas::FdModel<Self, NX, NU> (csrc/mas_models.hpp), e.g.
+ *                     struct Unicycle : FdModel<Unicycle, 3, 2> {
+ *                       MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) { ... }
+ *                       MAS_HD static double stage_cost(const double* x, const double* u, int t, const ModelParams& P) { ... }
+ *                       MAS_HD static double terminal_cost(const double* x, const ModelParams& P) { ... } };
+ *   struct_name     its name
+ *   source_root     tree that holds multi_agent_solver_amd/csrc and include (NULL: the tree this library was built in)
+ *   model_id        out: the id to put into mas_hip_problem_desc::model_id (>= 100)
+ * The struct is compiled with the ROCm compiler of the machine (hipcc; ~1.5 minutes: the host driver and every kernel template for
+ * this model, with the library's own options -- no contraction, IEEE division) into a plugin library, which is loaded into the
+ * process.  Needs hipcc at run time; MAS_HIP_ERR_INVALID with the compiler's messages in mas_hip_last_error(NULL) when the source
+ * does not compile.  Process-wide, thread-safe, not undone. */
+int mas_hip_register_model(const char* struct_source, const char* struct_name, const char* source_root, int* model_id);
 int mas_hip_model_default_params(int model_id, int horizon_steps, double* params16);
 int mas_hip_create(const mas_hip_problem_desc* desc, mas_hip_solver** out);
 int mas_hip_create_on_stream(const mas_hip_problem_desc* desc, void* hip_stream, mas_hip_solver** out);

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmas_hip.so")
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_STATE = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "mas_hip_abi_version", "mas_hip_device_count", "mas_hip_model_dims", "mas_hip_model_default_params",
+    "mas_hip_abi_version", "mas_hip_device_count", "mas_hip_model_dims", "mas_hip_model_default_params", "mas_hip_register_model",
     "mas_hip_create", "mas_hip_create_on_stream", "mas_hip_destroy", "mas_hip_last_error",
     "mas_hip_set_param", "mas_hip_check_params", "mas_hip_set_option",
     "mas_hip_set_initial_states_host", "mas_hip_set_controls_host",
@@ -99,6 +99,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     lib.mas_hip_last_error.restype = C.c_char_p
     lib.mas_hip_last_error.argtypes = [vp]
     lib.mas_hip_model_dims.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mas_hip_register_model.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
     lib.mas_hip_model_default_params.argtypes = [C.c_int, C.c_int, d]
     lib.mas_hip_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(vp)]
     lib.mas_hip_create_on_stream.argtypes = [C.POINTER(ProblemDesc), vp, C.POINTER(vp)]

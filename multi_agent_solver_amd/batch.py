@@ -339,6 +339,17 @@ class BatchSolver:
                                            algorithmic_bytes=buf[i].algorithmic_bytes) for i in range(min(n.value, 64))}
 
 
+def register_model(struct_source: str, struct_name: str, source_root: Optional[str] = None, lib=None) -> int:
+    """mas_hip_register_model: compile a user-defined workload (a struct deriving from mas::FdModel<Self, NX, NU>, csrc/mas_models.hpp)
+    against the kernel templates with the machine's hipcc, load it, and return its model id for BatchSolver(model_id, ...)."""
+    lib = lib or _capi.load()
+    mid = C.c_int()
+    rc = lib.mas_hip_register_model(struct_source.encode(), struct_name.encode(), source_root.encode() if source_root else None, C.byref(mid))
+    if rc != _capi.OK:
+        raise _capi.MasHipError(rc, (lib.mas_hip_last_error(None) or b"").decode())
+    return mid.value
+
+
 # ----------------------------------------------------------------- workload generators --
 def single_track_x0(N: int, track_radius: float = 20.0, first: int = 0, total: Optional[int] = None) -> np.ndarray:
     """Agent i of `total` at theta = 2*pi*i/total (examples/multi_agent_single_track.cpp:41-45,113-117);

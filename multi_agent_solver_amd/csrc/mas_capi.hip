@@ -5,8 +5,14 @@
 // with MAS_HIP_ERR_NO_DEVICE -- there is no CPU fallback in the product.
 #include "../../include/mas_hip.h"
 
+#include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <mutex>
 #include <new>
+#include <sstream>
+#include <dlfcn.h>
+#include <unistd.h>
 
 #include "mas_solver.hpp"
 
@@ -78,6 +84,69 @@ int comm_guarded(Fn&& fn) {
   } catch (const std::invalid_argument& e) { g_comm_error = e.what(); return MAS_HIP_ERR_INVALID;
   } catch (const std::exception& e) { g_comm_error = e.what(); return MAS_HIP_ERR_RUNTIME; }
 }
+// ---- user-defined workloads (mas_hip_register_model) ----
+// The reference takes a workload as callbacks (types.hpp:21-50); device code cannot call those, so a workload here is a struct of
+// static functions the kernel templates are instantiated with.  A new one does not need a rebuild of this library: its source is
+// compiled -- host driver and kernels, the very headers this library was built from -- into a plugin library by the ROCm compiler
+// at run time, loaded, and its factory entered in the registry that mas_hip_create consults.
+#if !defined(MAS_HOST_EMULATION)
+std::mutex g_register_mutex;
+std::string directory_of_this_library() {
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<const void*>(&directory_of_this_library), &info) || !info.dli_fname) return std::string();
+  std::string path = info.dli_fname;
+  const size_t cut = path.find_last_of('/');
+  return cut == std::string::npos ? std::string(".") : path.substr(0, cut);
+}
+bool file_exists(const std::string& path) { std::ifstream f(path); return f.good(); }
+std::string tail_of_file(const std::string& path, size_t bytes) {
+  std::ifstream f(path); std::stringstream ss; ss << f.rdbuf();
+  const std::string all = ss.str();
+  return all.size() > bytes ? all.substr(all.size() - bytes) : all;
+}
+int register_model_impl(const char* struct_source, const char* struct_name, const char* source_root, int* model_id) {
+  if (!struct_source || !struct_name || !model_id) { g_create_error = "null argument"; return MAS_HIP_ERR_INVALID; }
+  for (const char* c = struct_name; *c; ++c)
+    if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9' && c != struct_name) || *c == '_')) { g_create_error = "struct_name is not an identifier"; return MAS_HIP_ERR_INVALID; }
+  std::lock_guard<std::mutex> lock(g_register_mutex);
+  // the headers: <root>/multi_agent_solver_amd/csrc and <root>/include; by default the tree this library was built in
+  std::string root = source_root ? source_root : "";
+  if (root.empty()) { const std::string lib = directory_of_this_library(); root = lib + "/../.."; }
+  const std::string csrc = root + "/multi_agent_solver_amd/csrc", inc = root + "/include";
+  if (!file_exists(csrc + "/mas_solver.hpp") || !file_exists(inc + "/mas_dettrig.h")) { g_create_error = "kernel headers not found under " + root + " (pass source_root)"; return MAS_HIP_ERR_INVALID; }
+  char dir_template[] = "/tmp/mas_model_XXXXXX";
+  const char* dir = mkdtemp(dir_template);
+  if (!dir) { g_create_error = "mkdtemp failed"; return MAS_HIP_ERR_RUNTIME; }
+  const std::string d = dir, src = d + "/model.hip", so = d + "/model.so", log = d + "/build.log";
+  {
+    std::ofstream f(src);
+    f << "// generated by mas_hip_register_model\n#include \"mas_solver.hpp\"\nnamespace mas {\n" << struct_source << "\n}  // namespace mas\n"
+      << "extern \"C\" mas::SolverBase* mas_plugin_make(const mas::ProblemDesc* desc, void* stream) { return new mas::SolverImpl<mas::" << struct_name << ">(*desc, stream); }\n"
+      << "extern \"C\" void mas_plugin_dims(int* nx, int* nu) { *nx = mas::" << struct_name << "::NX; *nu = mas::" << struct_name << "::NU; }\n";
+  }
+  const char* env_cc = std::getenv("HIPCC");
+  const std::string cc = env_cc ? env_cc : (file_exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc");
+  // the options libmas_hip.so itself is built with (__graft_entry__.py): nothing is contracted, IEEE division and square root
+  const std::string cmd = "'" + cc + "' --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -shared -I'" + csrc + "' -I'" + inc + "' '" + src + "' -o '" + so + "' > '" + log + "' 2>&1";
+  if (std::system(cmd.c_str()) != 0 || !file_exists(so)) { g_create_error = "the model did not compile (" + log + "):\n" + tail_of_file(log, 2000); return MAS_HIP_ERR_INVALID; }
+  void* lib = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { g_create_error = std::string("dlopen of the compiled model failed: ") + dlerror(); return MAS_HIP_ERR_RUNTIME; }
+  mas::RegisteredModel rm;
+  rm.make = reinterpret_cast<mas::SolverBase* (*)(const mas::ProblemDesc*, void*)>(dlsym(lib, "mas_plugin_make"));
+  auto dims = reinterpret_cast<void (*)(int*, int*)>(dlsym(lib, "mas_plugin_dims"));
+  if (!rm.make || !dims) { dlclose(lib); g_create_error = "the compiled model lacks its factory"; return MAS_HIP_ERR_RUNTIME; }
+  dims(&rm.nx, &rm.nu);
+  if (rm.nx < 1 || rm.nx > 8 || rm.nu < 1 || rm.nu > 8) { dlclose(lib); g_create_error = "NX and NU must lie in 1 .. 8"; return MAS_HIP_ERR_INVALID; }
+  rm.library = lib; rm.name = struct_name;
+  mas::registered_models().push_back(rm);
+  *model_id = mas::kFirstRegisteredModel + static_cast<int>(mas::registered_models().size()) - 1;
+  std::remove(src.c_str()); std::remove(log.c_str());      // (model.so stays mapped; its directory entry is left for the process's lifetime)
+  return MAS_HIP_OK;
+}
+#else
+int register_model_impl(const char*, const char*, const char*, int*) { g_create_error = "the host emulation registers no models"; return MAS_HIP_ERR_RUNTIME; }
+#endif
+
 void select_device(int device) {
 #if !defined(MAS_HOST_EMULATION)
   MAS_HIP_CHECK(hipSetDevice(device));
@@ -96,6 +165,10 @@ int mas_hip_model_default_params(int model_id, int horizon_steps, double* params
   if (!params16 || !mas::model_dims(model_id, nullptr, nullptr)) return MAS_HIP_ERR_INVALID;
   mas::model_default_params(model_id, horizon_steps, params16);
   return MAS_HIP_OK;
+}
+int mas_hip_register_model(const char* struct_source, const char* struct_name, const char* source_root, int* model_id) {
+  try { return register_model_impl(struct_source, struct_name, source_root, model_id); }
+  catch (const std::exception& e) { g_create_error = e.what(); return MAS_HIP_ERR_RUNTIME; }
 }
 int mas_hip_create(const mas_hip_problem_desc* desc, mas_hip_solver** out) { return create_impl(desc, nullptr, out); }
 int mas_hip_create_on_stream(const mas_hip_problem_desc* desc, void* hip_stream, mas_hip_solver** out) { return create_impl(desc, hip_stream, out); }

@@ -73,12 +73,17 @@ struct FusedLayout {
   static_assert(RING > 0 ? HELPERS >= 1 : HELPERS <= 1, "RING == 0: no linearising helpers (at most the one wavefront that commits)");
 };
 
+// The hand-shake words between the wavefronts of a workgroup (ready[], consumed[], parts_done) are written with RELEASE and read with
+// ACQUIRE semantics at workgroup scope, so that the order "tile stores -> flag" / "flag -> tile loads" is the memory model's and does not
+// rest on the instruction order the scheduler happens to keep (on LDS both compile to the plain ds instruction plus the s_waitcnt
+// that was already there).
+__device__ __forceinline__ void lds_publish(int* word, int value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // one LDS word, re-read until `done(value)`; uniform over the wavefront
 template <class Pred>
-__device__ __forceinline__ bool lds_wait(const volatile int* word, Pred done, int* error) {
+__device__ __forceinline__ bool lds_wait(int* word, Pred done, int* error) {
   int spins = 0;
   for (;;) {
-    const int v = __builtin_amdgcn_readfirstlane(*word);
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (done(v)) return true;
     ++spins;
     if (spins > kFusedSpinLimit) { if ((threadIdx.x & 63) == 0 && error) atomicExch(error, 1); return false; }   // ~0.2 s
@@ -139,7 +144,7 @@ struct RingSource {
   }
   __device__ __forceinline__ const RowTile& make(const Raw& r, int, RowTile&) const { return r; }
   // step t's tile has arrived: if it was the last of its chunk, the helpers may reuse the slot
-  __device__ __forceinline__ void arrived(int t) const { if ((t & 3) == 0 && tid == 0) ctl->consumed[wave] = C - (t >> 2); }
+  __device__ __forceinline__ void arrived(int t) const { if ((t & 3) == 0 && tid == 0) lds_publish(&ctl->consumed[wave], C - (t >> 2)); }
 };
 
 // ---- models whose derivatives are all analytic (the identity LQR): every lane evaluates them in registers from x_t, u_t.  No
@@ -603,8 +608,8 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
     if (fr.D_dump && in && act) R::for_each([&](int e) { MAS_TILE_AT(fr.D_dump, ND, t, a, e) = Dl[e]; });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int before = 0;
-    if (l == 0) before = atomicAdd(&ctl->parts_done, 1);               // LDS atomic: the last of the three publishes the chunk
-    if (__builtin_amdgcn_readfirstlane(before) == 2 && l == 0) ctl->ready[0] = 1;
+    if (l == 0) before = __hip_atomic_fetch_add(&ctl->parts_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS atomic: the last of the three publishes the chunk
+    if (__builtin_amdgcn_readfirstlane(before) == 2 && l == 0) lds_publish(&ctl->ready[0], 1);
   };
   auto whole_chunk = [&](int n) {
     const int t = 4 * (C - 1 - n) + dt;
@@ -623,7 +628,7 @@ __device__ __forceinline__ void fused_helper_wave(const Dims& d, const ModelPara
     MAS_UNROLL for (int e = 0; e < ND; ++e) tile[e] = Dl[e];
     if (fr.D_dump && in && act) { MAS_UNROLL for (int e = 0; e < ND; ++e) MAS_TILE_AT(fr.D_dump, ND, t, a, e) = Dl[e]; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (l == 0) ctl->ready[n % RING] = n + 1;
+    if (l == 0) lds_publish(&ctl->ready[n % RING], n + 1);
   };
   if constexpr (kShareFirst) {
     if (h == 0) share_of_first_chunk(std::integral_constant<int, kGroup0>{}, true);
@@ -727,7 +732,7 @@ mas_linearise_riccati_kernel(Dims d, ModelParams P, double* __restrict__ X, doub
     if (!any_act) return;
     const int al0 = wave * 4 + (lane >> 4);
     if (__ballot(ctl->act[al0] != 0) == 0ull) {                       // none of this wavefront's four agents is active: the helpers never wait for it
-      if (lane == 0) ctl->consumed[wave] = 0x7fffffff;
+      if (lane == 0) lds_publish(&ctl->consumed[wave], 0x7fffffff);
       return;
     }
 #if !defined(MAS_FUSED_NO_PRIO)

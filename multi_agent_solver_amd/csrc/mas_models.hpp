@@ -41,6 +41,30 @@ struct NoConstraints {
 };
 
 // ---------------------------------------------------------------------------------------
+// Base of a USER-DEFINED workload (mas_hip_register_model, include/mas_hip.h): like an OCP of the reference that sets only dynamics,
+// stage_cost and terminal_cost (types.hpp:21-50) and leaves every derivative hook empty, so that OCP::initialize_problem installs the
+// finite-difference defaults (ocp.hpp:117-135).  A model derives from FdModel<Self, NX, NU> and provides
+//     MAS_HD static void   dynamics(const double* x, const double* u, double* dxdt, const ModelParams& P);
+//     MAS_HD static double stage_cost(const double* x, const double* u, int t, const ModelParams& P);
+//     MAS_HD static double terminal_cost(const double* x, const ModelParams& P);
+// (P.p[0..15] are the problem's constants, mas_hip_problem_desc::params; sin / cos / tan as mas_dt_sin / mas_dt_cos / mas_dt_tan.)
+// It may override what the built-in models set: default_bounds + kDefaultBounds, kZeroTerminal, Ctl / prepare / dynamics_c (the part of
+// f(x, u) that depends on the zero-order-hold control alone, evaluated once per RK4 step), kRolloutLevels / state_level.
+struct NoCtl {};
+template <class Self, int NX_, int NU_>
+struct FdModel : NoConstraints {
+  static constexpr int NX = NX_, NU = NU_;
+  static constexpr bool kAnalyticA = false, kAnalyticB = false, kAnalyticLx = false, kAnalyticLu = false,
+                        kAnalyticLxx = false, kAnalyticLuu = false, kAnalyticLux = false, kAnalyticTerm = false;
+  static constexpr bool kZeroTerminal = false;
+  static constexpr bool kDefaultBounds = false;
+  MAS_HD static void default_bounds(double*, double*) {}
+  using Ctl = NoCtl;
+  MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
+  MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl&, double* d, const ModelParams& P) { Self::dynamics(x, u, d, P); }
+};
+
+// ---------------------------------------------------------------------------------------
 // Single-track circular-track workload.
 //   dynamics: examples/models/single_track_model.hpp:23-44
 //   cost / bounds / constants: examples/multi_agent_single_track.cpp:46-67,103-110
@@ -83,7 +107,6 @@ struct SingleTrack : NoConstraints {
 // ---------------------------------------------------------------------------------------
 // Identity LQR: examples/multi_agent_lqr.cpp:21-76 (A=B=Q=R=Qf=I, n_x=n_u=4), every
 // derivative analytic (:35-41,46-71).
-struct NoCtl {};
 
 struct LqrIdentity : NoConstraints {
   static constexpr int NX = 4, NU = 4;

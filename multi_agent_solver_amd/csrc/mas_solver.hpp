@@ -952,7 +952,18 @@ std::unique_ptr<SolverBase> make_solver_ilp(const ProblemDesc& desc, void* exter
   }
 }
 #else
+// workloads registered at run time (mas_hip_register_model): a model struct compiled against these very templates into a plugin
+// library whose factory is entered here; ids start at kFirstRegisteredModel
+constexpr int kFirstRegisteredModel = 100;
+struct RegisteredModel { int nx = 0, nu = 0; SolverBase* (*make)(const ProblemDesc*, void*) = nullptr; void* library = nullptr; std::string name; };
+inline std::vector<RegisteredModel>& registered_models() { static std::vector<RegisteredModel> models; return models; }
+inline const RegisteredModel* registered_model(int model_id) {
+  const auto& r = registered_models();
+  const int k = model_id - kFirstRegisteredModel;
+  return (k >= 0 && k < static_cast<int>(r.size())) ? &r[static_cast<size_t>(k)] : nullptr;
+}
 inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* external_stream) {
+  if (const RegisteredModel* rm = registered_model(desc.model_id)) return std::unique_ptr<SolverBase>(rm->make(&desc, external_stream));
   switch (desc.model_id) {
     case 1: return std::make_unique<SolverImpl<SingleTrack>>(desc, external_stream);
     case 2: return make_solver_ilp(desc, external_stream);
@@ -967,6 +978,9 @@ inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* ex
 
 inline bool model_dims(int model_id, int* nx, int* nu) {
   int a = 0, b = 0;
+#if !defined(MAS_TU_MODELS_ILP)
+  if (const RegisteredModel* rm = registered_model(model_id)) { if (nx) *nx = rm->nx; if (nu) *nu = rm->nu; return true; }
+#endif
   switch (model_id) {
     case 1: a = SingleTrack::NX; b = SingleTrack::NU; break;
     case 2: a = LqrIdentity::NX; b = LqrIdentity::NU; break;

@@ -1,0 +1,111 @@
+"""User-defined workloads (mas_hip_register_model): the reference takes a workload as callbacks (types.hpp:21-50) and finite-differences
+every derivative hook an example leaves empty (ocp.hpp:117-135); here a workload is a struct of static functions, and a NEW one is
+compiled against the kernel templates at run time -- no rebuild of libmas_hip.so.
+
+1. The single-track workload written AGAIN as a user model (plain FdModel: no hoisted tan(delta), no four-lane RK4, no dependency
+   levels, no skipped zero terminal cost) must give the bits of the built-in model 1 and of the oracle, for every strategy: same
+   arithmetic per evaluation, other kernel forms.
+2. A workload the library has never seen (a cart with quadratic drag: two states, one control) against the SECOND restatement of the
+   reference's solve, oracle/ilqr_numpy.py, which takes Python callbacks like the reference takes std::function: finite-difference-noise
+   tolerance, as in tests/test_oracle_numpy_crosscheck.py.
+3. A struct that does not compile: MAS_HIP_ERR_INVALID with the compiler's message."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import run_batch
+
+pytestmark = pytest.mark.gpu
+
+USER_SINGLE_TRACK = r"""
+struct UserSingleTrack : FdModel<UserSingleTrack, 4, 2> {
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {     // examples/models/single_track_model.hpp:23-44
+    const double psi = x[2], v = x[3], L = P.p[6];
+    d[0] = v * mas_dt_cos(psi);
+    d[1] = v * mas_dt_sin(psi);
+    d[2] = (v * mas_dt_tan(u[0])) / L;
+    d[3] = u[1];
+  }
+  MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {        // examples/multi_agent_single_track.cpp:46-64
+    const double dist = fabs(sqrt(s[0] * s[0] + s[1] * s[1]) - P.p[0]);
+    const double se = s[3] - P.p[1];
+    return P.p[2] * dist * dist + P.p[3] * se * se + P.p[4] * c[0] * c[0] + P.p[5] * c[1] * c[1];
+  }
+  MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
+};
+"""
+
+DRAG_CART = r"""
+struct DragCart : FdModel<DragCart, 2, 1> {
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    d[0] = x[1];
+    d[1] = u[0] - P.p[0] * x[1] * fabs(x[1]);
+  }
+  MAS_HD static double stage_cost(const double* x, const double* u, int, const ModelParams& P) {
+    const double e = x[0] - P.p[1];
+    return e * e + 0.1 * x[1] * x[1] + 0.01 * u[0] * u[0];
+  }
+  MAS_HD static double terminal_cost(const double* x, const ModelParams& P) { const double e = x[0] - P.p[1]; return 10.0 * e * e + x[1] * x[1]; }
+};
+"""
+
+SINGLE_TRACK_PARAMS = [20.0, 5.0, 1.0, 1.0, 0.001, 0.001, 2.5] + [0.0] * 9
+
+
+@pytest.fixture(scope="module")
+def gpu_lib(product_lib):
+    assert product_lib.mas_hip_device_count() > 0
+    return product_lib
+
+
+@pytest.fixture(scope="module")
+def user_single_track(gpu_lib):
+    from multi_agent_solver_amd.batch import register_model
+    return register_model(USER_SINGLE_TRACK, "UserSingleTrack", lib=gpu_lib)          # ~1.5 minutes of hipcc
+
+
+@pytest.mark.parametrize("strategy,outer", [("sequential", 3), ("trustregion", 3), ("linesearch", 2), ("centralized", 1), ("centralized_dense", 1)])
+def test_single_track_rewritten_as_a_user_model(gpu_lib, oracle, user_single_track, strategy, outer):
+    assert user_single_track >= 100
+    N, T = (6, 12) if strategy == "centralized_dense" else (70, 30)
+    rng = np.random.default_rng(3)
+    x0 = oracle.single_track_x0(N) + 0.05 * rng.standard_normal((N, 4))
+    mine = run_batch(gpu_lib, user_single_track, x0, None, T, 0.5, strategy, max_outer=outer, params=np.array(SINGLE_TRACK_PARAMS))
+    builtin = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy, max_outer=outer)
+    for key in ("cost", "X", "U", "iters", "status"):
+        assert np.array_equal(mine[key], builtin[key]), key
+    assert mine["total_cost"] == builtin["total_cost"] and mine["stats"]["reg_events"] == builtin["stats"]["reg_events"]
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy=strategy, max_outer=outer)
+    assert np.array_equal(mine["cost"], o["cost"]) and np.array_equal(mine["X"], o["X"]) and np.array_equal(mine["U"], o["U"])
+    assert mine["iters"].tolist() == o["iters"].tolist()
+
+
+def test_a_workload_the_library_has_never_seen(gpu_lib):
+    from multi_agent_solver_amd.batch import register_model
+    from oracle import ilqr_numpy as inp
+    mid = register_model(DRAG_CART, "DragCart", lib=gpu_lib)
+    drag, target, T, dt = 0.3, 2.0, 20, 0.1
+    params = np.array([drag, target] + [0.0] * 14)
+    x0 = np.array([[0.0, 0.0], [0.5, -0.2], [-1.0, 1.0]])
+    e = run_batch(gpu_lib, mid, x0, None, T, dt, "single", params=params, no_input_bounds=True)
+    for a in range(x0.shape[0]):
+        p = inp.Problem(lambda x, u: np.array([x[1], u[0] - drag * x[1] * abs(x[1])]),
+                        lambda x, u, t: (x[0] - target) ** 2 + 0.1 * x[1] * x[1] + 0.01 * u[0] * u[0],
+                        lambda x: 10.0 * (x[0] - target) ** 2 + x[1] * x[1], x0[a], T, dt, 1)
+        r = inp.solve(p, np.zeros((1, T)))
+        assert abs(e["cost"][a] - r["cost"]) <= 5e-3 * abs(r["cost"]), (a, e["cost"][a], r["cost"])         # two FD solves: noise-level agreement
+        assert abs(int(e["iters"][a]) - r["iterations"]) <= 1
+        assert np.abs(e["X"][a].T - r["X"]).max() <= 5e-2
+
+
+def test_a_model_that_does_not_compile_is_refused_with_the_compilers_words(gpu_lib):
+    from multi_agent_solver_amd._capi import MasHipError, ERR_INVALID
+    from multi_agent_solver_amd.batch import register_model
+    with pytest.raises(MasHipError) as err:
+        register_model("struct Broken : FdModel<Broken, 2, 1> { this is not C++ };", "Broken", lib=gpu_lib)
+    assert err.value.code == ERR_INVALID and "error" in str(err.value)
+    with pytest.raises(MasHipError):
+        register_model("struct X {};", "not an identifier", lib=gpu_lib)

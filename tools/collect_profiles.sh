@@ -11,6 +11,7 @@ W=${1:-c3}; TAG=${2:-r4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
 rm -rf "$OUT"; mkdir -p "$OUT"
+python3 -c "from multi_agent_solver_amd.source_hash import source_hash; print(source_hash())" > "$OUT/source_hash.txt"      # the sources these counters are collected from
 python3 tools/one_run.py "$W" --algorithmic "$OUT/algorithmic.json" > "$OUT/algorithmic.log" 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --workload "$W" --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-parity > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats pass done"
@@ -25,3 +26,4 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
   echo "sq set $i done"
 done
 python3 tools/summarise_profiles.py "$W" "$TAG" "$OUT"
+# (profiles/ does not travel back from the GPU box: run the same summarise command on the merged gpurun_out/ directory afterwards)

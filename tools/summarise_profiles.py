@@ -74,7 +74,8 @@ def counters(csv_path):
 sys.path.insert(0, ROOT)
 from multi_agent_solver_amd.source_hash import source_hash  # noqa: E402
 
-meta = {"workload": W, "commit": commit_id(), "source_hash": source_hash(), "collected_by": "tools/collect_profiles.sh " + W + " " + TAG}
+_stamp = os.path.join(D, "source_hash.txt")      # written on the GPU box at collection time; the hash of the sources at summarise time only without it
+meta = {"workload": W, "commit": commit_id(), "source_hash": (open(_stamp).read().strip() if os.path.exists(_stamp) else source_hash()), "collected_by": "tools/collect_profiles.sh " + W + " " + TAG}
 alg = json.load(open(os.path.join(D, "algorithmic.json")))
 
 # ---- 1. kernel stats of the bench run
