@@ -51,7 +51,8 @@ struct DenseChipWs {                         // device arrays of the stacked pro
   double *c, *pre, *cx5, *cu5, *cx6, *cu6;   // DenseTables of the current time step
   double *lx, *lu, *lxx, *luu, *lux;
   double *k, *K;                             // [T m], [T m n]
-  double *V, *vx, *qx, *qu, *qxx, *qux, *quu, *Rr, *Lt, *inv, *tmp_xx, *tmp_ux, *V3, *KtQuu, *gs;
+  double *V, *vx, *qx, *qu, *qxx, *qux, *quu, *Rr, *Lt, *SD, *inv, *tmp_xx, *tmp_ux, *V3, *KtQuu, *gs;
+  int* rung_state;                           // [16] blocked ladder: 0 = being factorised, 1 = failed, 2 = factorised
   long long* host_word;                      // pinned: (iterations << 8) | stop, stored once per iteration
 };
 
@@ -426,7 +427,7 @@ __global__ void dc_assemble2(DenseChipWs w, int N) {
 // LDS from a row-major copy; inside the panel the columns follow one another (pivot, division, the later columns' next term), two
 // barriers a column.  Every thread keeps the running sum of squares of its row for its own pivot.
 constexpr int kDcPanel = 8;
-static __global__ void __launch_bounds__(512) dc_ladder(DenseChipWs w, int m) {
+static __global__ void __launch_bounds__(512) dc_ladder(DenseChipWs w, int m, int first_rung) {
   extern __shared__ double dc_lds[];
   __shared__ double sh_x[2], tri[kDcPanel * kDcPanel]; __shared__ int sh_fail, sh_go;
   DenseChipState* S = w.S;
@@ -436,13 +437,13 @@ static __global__ void __launch_bounds__(512) dc_ladder(DenseChipWs w, int m) {
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   const size_t m2 = static_cast<size_t>(m) * m;
   double* R = w.Rr + static_cast<size_t>(blockIdx.x) * m2; double* LT = w.Lt + static_cast<size_t>(blockIdx.x) * m2;
-  for (int rung = static_cast<int>(blockIdx.x); rung <= kRegLadderMax; rung += kDenseChipRungs) {
+  for (int rung = first_rung + static_cast<int>(blockIdx.x); rung <= kRegLadderMax; rung += kDenseChipRungs) {
     if (tid == 0) {
       int go = 1;
       const unsigned long long below = (rung >= 64) ? ~0ull : ((1ull << rung) - 1ull);
       for (int spins = 0;; ++spins) {
         if (__hip_atomic_load(&S->rung_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rung) { go = 0; break; }
-        if (rung < kDenseChipRungs || rung >= 64 || spins > (1 << 16)) break;
+        if (rung < first_rung + kDenseChipRungs || rung >= 64 || spins > (1 << 16)) break;
         if ((__hip_atomic_load(rung_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & below) == below) break;     // every lower rung has failed: this one is needed
         __builtin_amdgcn_s_sleep(8);
       }
@@ -517,6 +518,112 @@ static __global__ void __launch_bounds__(512) dc_ladder(DenseChipWs w, int m) {
     if (tid == 0 && rung < 64) __hip_atomic_fetch_or(rung_failed, 1ull << rung, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
+}
+
+// ---- the same sixteen factorisations spread over the CHIP: blocked by panels of kDcBlock columns ----
+// For an entry (r, k) of the factor the reference forms  a = M(r,k) + sum_{j<k} (-L(k,j)) L(r,j)  with j ascending.  The sum is taken panel by
+// panel: once panel p (columns pB .. pB+B-1) is final, EVERY entry to its right adds that panel's B terms, in j order, to its running value
+// (dc_llt_update: 64 x 64 tiles of the trailing triangle of all sixteen rungs, 4 x 4 entries per thread) -- the terms reach every entry
+// in the order of the serial loop -- and only the panel itself (dc_llt_panel: one workgroup per rung, thread = row, pivot / division /
+// next column's term, two barriers a column) is a chain.  m / B panel steps instead of m column steps: 3.4 -> 0.8 ms per 512 x 512 ladder.
+// The running sum of squares of row r (for its own pivot: x = M(r,r) - s, s from 0.0 in j order) is kept in SD by the panel kernel.
+constexpr int kDcBlock = 32;
+static __global__ void dc_llt_init(DenseChipWs w, int m) {
+  if (w.S->stop) return;
+  const size_t m2 = static_cast<size_t>(m) * m, total = m2 * kDenseChipRungs;
+  for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int rung = static_cast<int>(e / m2); const size_t q = e % m2;
+    double v = w.quu[q];
+    if (q % (static_cast<size_t>(m) + 1) == 0) { double reg = 1e-6; for (int i = 0; i < rung; ++i) { v += reg; reg *= 10.0; } }
+    w.Rr[e] = v;
+    if (q < static_cast<size_t>(m)) w.SD[static_cast<size_t>(rung) * m + q] = 0.0;
+    if (q == 0) w.rung_state[rung] = 0;
+  }
+}
+static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m, int p) {
+  __shared__ double sh_x[2], tri[kDcBlock * kDcBlock]; __shared__ int sh_fail;
+  DenseChipState* S = w.S;
+  const int rung = static_cast<int>(blockIdx.x);
+  if (S->stop || w.rung_state[rung] != 0) return;
+  const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
+  double* R = w.Rr + static_cast<size_t>(rung) * m * m; double* SD = w.SD + static_cast<size_t>(rung) * m;
+  const int k0 = p * kDcBlock, pw = min(kDcBlock, m - k0);
+  double a[2][kDcBlock], sq[2];
+  MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+    const int r = tid + slot * nt;
+    sq[slot] = (r < m) ? SD[r] : 0.0;
+    MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) a[slot][q] = (q < pw && r > k0 + q && r < m) ? R[static_cast<size_t>(k0 + q) * m + r] : 0.0;
+  }
+  if (tid == 0) sh_fail = 0;
+  __syncthreads();
+  bool failed = false;
+  MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) {
+    const int k = k0 + q;
+    if (q < pw && !failed) {                                             // (uniform)
+      if (tid == k % nt) {
+        double x = R[static_cast<size_t>(k) * m + k];
+        if (k > 0) x = x - ((k / nt) ? sq[1] : sq[0]);
+        if (x <= 0.0) sh_fail = 1;                                      // (NaN pivots pass, like Eigen)
+        else { x = sqrt(x); R[static_cast<size_t>(k) * m + k] = x; sh_x[q & 1] = x; }
+      }
+      __syncthreads();
+      if (sh_fail) failed = true;
+      if (!failed) {
+        const double x = sh_x[q & 1];
+        double v[2] = {0.0, 0.0};
+        MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+          const int r = tid + slot * nt;
+          if (r > k && r < m) {
+            v[slot] = a[slot][q] / x;
+            R[static_cast<size_t>(k) * m + r] = v[slot];
+            sq[slot] += v[slot] * v[slot];
+            if (r < k0 + kDcBlock) tri[(r - k0) * kDcBlock + q] = -v[slot];
+          }
+        }
+        __syncthreads();
+        MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+          const int r = tid + slot * nt;
+          if (r > k && r < m) {
+            MAS_UNROLL for (int q2 = q + 1; q2 < kDcBlock; ++q2) { if (q2 < pw && k0 + q2 < r) { const double pr = tri[q2 * kDcBlock + q] * v[slot]; a[slot][q2] += pr; } }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (failed) { if (tid == 0) { w.rung_state[rung] = 1; __hip_atomic_fetch_or(&S->rung_failed, 1ull << rung, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
+  MAS_UNROLL for (int slot = 0; slot < 2; ++slot) { const int r = tid + slot * nt; if (r < m) SD[r] = sq[slot]; }
+  if (k0 + pw >= m && tid == 0) { w.rung_state[rung] = 2; atomicMin(&S->rung_best, rung); }
+}
+static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m, int p) {
+  __shared__ double Lr[kDcBlock][64 + 4], Lk[kDcBlock][64 + 4];
+  const int rung = static_cast<int>(blockIdx.y);
+  if (w.S->stop || w.rung_state[rung] != 0) return;
+  double* R = w.Rr + static_cast<size_t>(rung) * m * m;
+  const int k0p = p * kDcBlock, c0 = k0p + kDcBlock;                     // the panel's first column; first column of the trailing part
+  if (c0 >= m) return;
+  const int nb = (m - c0 + 63) / 64;                                    // 64-wide blocks of the trailing part; tiles (ti >= tk)
+  int tile = static_cast<int>(blockIdx.x), ti = 0;
+  while (tile > ti) { tile -= ti + 1; ++ti; }                           // tile number -> (ti, tk) of the lower triangle of blocks
+  const int tk = tile;
+  if (ti >= nb) return;
+  const int r0 = c0 + 64 * ti, kk0 = c0 + 64 * tk;
+  const int tid = static_cast<int>(threadIdx.x), tx = tid & 15, ty = tid >> 4;
+  for (int e = tid; e < kDcBlock * 64; e += 256) {
+    const int j = e >> 6, c = e & 63;
+    Lr[j][c] = (r0 + c < m) ? R[static_cast<size_t>(k0p + j) * m + r0 + c] : 0.0;
+    Lk[j][c] = (kk0 + c < m) ? -R[static_cast<size_t>(k0p + j) * m + kk0 + c] : 0.0;
+  }
+  __syncthreads();
+  double acc[4][4];
+  MAS_UNROLL for (int b = 0; b < 4; ++b) { MAS_UNROLL for (int a = 0; a < 4; ++a) { const int r = r0 + tx * 4 + a, k = kk0 + ty * 4 + b; acc[a][b] = (r > k && r < m) ? R[static_cast<size_t>(k) * m + r] : 0.0; } }
+  for (int j = 0; j < kDcBlock; ++j) {
+    double lr[4], lk[4];
+    MAS_UNROLL for (int a = 0; a < 4; ++a) lr[a] = Lr[j][tx * 4 + a];
+    MAS_UNROLL for (int b = 0; b < 4; ++b) lk[b] = Lk[j][ty * 4 + b];
+    MAS_UNROLL for (int b = 0; b < 4; ++b) { MAS_UNROLL for (int a = 0; a < 4; ++a) { const double pr = lk[b] * lr[a]; acc[a][b] += pr; } }
+  }
+  MAS_UNROLL for (int b = 0; b < 4; ++b) { MAS_UNROLL for (int a = 0; a < 4; ++a) { const int r = r0 + tx * 4 + a, k = kk0 + ty * 4 + b; if (r > k && r < m) R[static_cast<size_t>(k) * m + r] = acc[a][b]; } }
 }
 
 // Quu_reg^-1 = LLT::solve(I) (ilqr.hpp:183; llt_solve_identity): `cols` identity columns per workgroup, their vectors in LDS

@@ -101,6 +101,7 @@ class SolverBase {
     bool central_one_xcd = true;            // its working workgroups on one XCD
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
     bool fused_trust = true;                // chained trust-region epilogue inside the fused kernel (four-state FD models); false: the five-kernel round
+    bool dense_ladder_blocked = true;       // chip-wide literal solve: the ladder's sixteen LLTs blocked by panels across the chip; false: one workgroup per rung, column by column
     bool dense_chip = true;                 // the literal stacked solve as chip-wide launches (mas_dense_chip.hpp); false: one workgroup (mas_dense.hpp, <= 64 agents)
     int central_combine = 1, central_wpb = kCentralWavesPerBlock, central_peek = 1;
     bool set(const std::string& key, long long v) {
@@ -117,6 +118,7 @@ class SolverBase {
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
       else if (key == "dense_chip") dense_chip = v != 0;
       else if (key == "fused_trust") fused_trust = v != 0;
+      else if (key == "dense_ladder_blocked") dense_ladder_blocked = v != 0;
       else if (key == "central_combine") central_combine = static_cast<int>(v);
       else if (key == "central_peek") central_peek = static_cast<int>(v);
       else if (key == "central_wpb") { if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) central_wpb = static_cast<int>(v); else return false; }
@@ -126,7 +128,7 @@ class SolverBase {
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
       static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
-                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust"};
+                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust", "dense_ladder_blocked"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
         for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
