@@ -554,6 +554,8 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
     sq[slot] = (r < m) ? SD[r] : 0.0;
     MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) a[slot][q] = (q < pw && r > k0 + q && r < m) ? R[static_cast<size_t>(k0 + q) * m + r] : 0.0;
   }
+  __shared__ double diag[kDcBlock];                                      // M(k,k) of the panel's columns, fetched ahead of the chain
+  if (tid < pw) diag[tid] = R[static_cast<size_t>(k0 + tid) * m + k0 + tid];
   if (tid == 0) sh_fail = 0;
   __syncthreads();
   bool failed = false;
@@ -561,7 +563,7 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
     const int k = k0 + q;
     if (q < pw && !failed) {                                             // (uniform)
       if (tid == k % nt) {
-        double x = R[static_cast<size_t>(k) * m + k];
+        double x = diag[q];
         if (k > 0) x = x - ((k / nt) ? sq[1] : sq[0]);
         if (x <= 0.0) sh_fail = 1;                                      // (NaN pivots pass, like Eigen)
         else { x = sqrt(x); R[static_cast<size_t>(k) * m + k] = x; sh_x[q & 1] = x; }
@@ -660,10 +662,17 @@ static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int
     const int rows = m - 1 - i;
     for (int e = tid; e < rows * nc; e += nt) { const int r = i + 1 + e / nc, c = e % nc; pr_[r * ld + c] = Li[r] * o[r * ld + c]; }
     __syncthreads();
-    if (tid < nc) {
+    if (tid < nc) {                                                      // the chain: eight products requested while the eight before them are added
       double b = 0.0;
       int r = i + 1;
-      for (; r + 8 <= m; r += 8) { double t8[8]; MAS_UNROLL for (int q = 0; q < 8; ++q) t8[q] = pr_[(r + q) * ld + tid]; MAS_UNROLL for (int q = 0; q < 8; ++q) b += t8[q]; }
+      double nx8[8];
+      if (r + 8 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = pr_[(r + q) * ld + tid]; }
+      for (; r + 8 <= m; r += 8) {
+        double t8[8];
+        MAS_UNROLL for (int q = 0; q < 8; ++q) t8[q] = nx8[q];
+        if (r + 16 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = pr_[(r + 8 + q) * ld + tid]; }
+        MAS_UNROLL for (int q = 0; q < 8; ++q) b += t8[q];
+      }
       for (; r < m; ++r) b += pr_[r * ld + tid];
       o[i * ld + tid] = (o[i * ld + tid] - b) * (1.0 / Li[i]);
     }

@@ -589,16 +589,17 @@ def test_literal_centralised_solve_against_the_committed_curve(gpu_lib, oracle):
             assert int(e["iters"][0]) == iterations, strategy
 
 
-@pytest.mark.parametrize("N", [128, 256])
-def test_literal_centralised_solve_at_config2s_size(gpu_lib, oracle, N):
+@pytest.mark.parametrize("N,blocked", [(128, 1), (128, 0), (256, 1)])
+def test_literal_centralised_solve_at_config2s_size(gpu_lib, oracle, N, blocked):
     """BASELINE configs[1] -- 256 agents, H = 100 -- under the reference's LITERAL algorithm: n = 1024 stacked states, m = 512 stacked controls,
-    eight iterations of a dense Riccati recursion, 6 s on the device.  The oracle's structured restatement needs ten minutes of eight cores
+    eight iterations of a dense Riccati recursion, 5 s on the device.  The oracle's structured restatement needs ten minutes of eight cores
     there, so the comparison is with its committed vectors (tests/golden/centralized_dense_large.json, tools/make_dense_goldens.py):
     per-agent costs and the total bit for bit, SHA-256 of the trajectories and controls, iterations, rungs of the ladder."""
     import hashlib
     import json
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "centralized_dense_large.json")))["cases"][str(N)]
-    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(N), None, g["horizon"], g["dt"], "centralized_dense")
+    # (blocked: the ladder's sixteen LLTs factorised across the chip panel by panel, m >= 256; 0: one workgroup per rung, column by column)
+    e = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK, oracle.single_track_x0(N), None, g["horizon"], g["dt"], "centralized_dense", options={"dense_ladder_blocked": blocked})
     assert float(e["total_cost"]).hex() == g["total_cost"]
     assert [float(v).hex() for v in e["cost"]] == g["cost"]
     assert int(e["iters"][0]) == g["iterations"] and e["stats"]["reg_events"] == g["reg_events"]
