@@ -566,7 +566,7 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
         double x = diag[q];
         if (k > 0) x = x - ((k / nt) ? sq[1] : sq[0]);
         if (x <= 0.0) sh_fail = 1;                                      // (NaN pivots pass, like Eigen)
-        else { x = sqrt(x); R[static_cast<size_t>(k) * m + k] = x; sh_x[q & 1] = x; }
+        else { x = sqrt(x); diag[q] = x; sh_x[q & 1] = x; }
       }
       __syncthreads();
       if (sh_fail) failed = true;
@@ -577,16 +577,18 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
           const int r = tid + slot * nt;
           if (r > k && r < m) {
             v[slot] = a[slot][q] / x;
-            R[static_cast<size_t>(k) * m + r] = v[slot];
+            a[slot][q] = v[slot];                                       // (the column's entries leave for memory behind the loop: a store in front of a barrier makes the barrier wait for it)
             sq[slot] += v[slot] * v[slot];
-            if (r < k0 + kDcBlock) tri[(r - k0) * kDcBlock + q] = -v[slot];
+            if (r < k0 + kDcBlock) tri[q * kDcBlock + (r - k0)] = -v[slot];      // [column][row of the panel]: the next loop reads one column's entries side by side
           }
         }
         __syncthreads();
         MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
           const int r = tid + slot * nt;
           if (r > k && r < m) {
-            MAS_UNROLL for (int q2 = q + 1; q2 < kDcBlock; ++q2) { if (q2 < pw && k0 + q2 < r) { const double pr = tri[q2 * kDcBlock + q] * v[slot]; a[slot][q2] += pr; } }
+            // every later column of the panel takes its next term -(L(k0+q2, k)) L(r, k); entries on or above the diagonal (k0 + q2 >= r) and
+            // beyond the panel's width are never read again, so nothing is tested here and the 31 LDS reads travel together
+            MAS_UNROLL for (int q2 = q + 1; q2 < kDcBlock; ++q2) { const double pr = tri[q * kDcBlock + q2] * v[slot]; a[slot][q2] += pr; }
           }
         }
       }
@@ -594,7 +596,12 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
   }
   __syncthreads();
   if (failed) { if (tid == 0) { w.rung_state[rung] = 1; __hip_atomic_fetch_or(&S->rung_failed, 1ull << rung, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
-  MAS_UNROLL for (int slot = 0; slot < 2; ++slot) { const int r = tid + slot * nt; if (r < m) SD[r] = sq[slot]; }
+  MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+    const int r = tid + slot * nt;
+    if (r < m) SD[r] = sq[slot];
+    MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) { if (q < pw && r > k0 + q && r < m) R[static_cast<size_t>(k0 + q) * m + r] = a[slot][q]; }
+  }
+  if (tid < pw) R[static_cast<size_t>(k0 + tid) * m + k0 + tid] = diag[tid];
   if (k0 + pw >= m && tid == 0) { w.rung_state[rung] = 2; atomicMin(&S->rung_best, rung); }
 }
 static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m, int p) {
@@ -628,12 +635,16 @@ static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m
   MAS_UNROLL for (int b = 0; b < 4; ++b) { MAS_UNROLL for (int a = 0; a < 4; ++a) { const int r = r0 + tx * 4 + a, k = kk0 + ty * 4 + b; if (r > k && r < m) R[static_cast<size_t>(k) * m + r] = acc[a][b]; } }
 }
 
-// Quu_reg^-1 = LLT::solve(I) (ilqr.hpp:183; llt_solve_identity): `cols` identity columns per workgroup, their vectors in LDS
-// ([row][col], odd stride).  Forward substitution right-looking with the rows dealt over the threads (o[r] -= b L(r,i) for all r > i at
-// step i: the subtractions reach every o[r] in the order i = 0, 1, ... of the serial loop; steps before the workgroup's first column
-// subtract b = 0 and are skipped), backward substitution one thread per column (the dot product over r ascending from 0.0 needs every
-// o[r] final: a serial chain of additions by construction -- its products are formed by all threads first).
-static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int cols) {
+// Quu_reg^-1 = LLT::solve(I) (ilqr.hpp:183; llt_solve_identity): 2^cshift identity columns per workgroup.
+// Forward substitution right-looking with the rows dealt over the threads: thread r keeps ITS row of the columns' vectors in registers; at
+// step i the owner of row i scales it (o[i] *= 1 / L(i,i)) and publishes it through LDS, every row below subtracts b L(r,i) -- the
+// subtractions reach every entry in the order i = 0, 1, ... of the serial loop; steps before the workgroup's first column subtract b = 0
+// and are skipped.  One barrier a step (the published row alternates between two LDS rows), L(r,i) requested a step ahead.
+// Backward substitution: o[i] = (o[i] - sum_{r>i} L(r,i) o[r]) / L(i,i) with the sum from 0.0 over r ascending -- its FIRST term is the row
+// that has only just become final, so the sum is a serial chain by construction (m^2 / 2 dependent additions per column).  One lane per
+// column walks it; the products of step i - 1 (all but that first term) are formed by the OTHER wavefronts while the chain of step i runs.
+constexpr int kDcSolveMaxCols = 16;
+static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int cshift) {
   extern __shared__ double dc_lds[];
   DenseChipState* S = w.S;
   if (S->stop) return;
@@ -641,40 +652,67 @@ static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int
   if (best == INT_MAX) { if (blockIdx.x == 0 && threadIdx.x == 0) S->failed = 1; return; }
   const double* R = w.Rr + static_cast<size_t>(best % kDenseChipRungs) * m * m;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
-  const int c0 = static_cast<int>(blockIdx.x) * cols, nc = min(cols, m - c0), ld = cols + 1;
+  const int cols = 1 << cshift, ld = cols + 1;
+  const int c0 = static_cast<int>(blockIdx.x) * cols, nc = min(cols, m - c0);
   if (nc <= 0) return;
-  double* o = dc_lds;
-  for (int e = tid; e < m * nc; e += nt) { const int r = e / nc, c = e % nc; o[r * ld + c] = (r == c0 + c) ? 1.0 : 0.0; }
+  double* o = dc_lds;                                                   // [m][ld] the columns' vectors
+  double* prA = o + static_cast<size_t>(m) * ld; double* prB = prA + static_cast<size_t>(m) * ld;      // products of the backward substitution, two steps
+  double* ainv = prB + static_cast<size_t>(m) * ld;                     // [m] 1 / L(i,i)
+  double* brow = ainv + m;                                              // [2][cols] the scaled row of the current step
+  for (int i = tid; i < m; i += nt) ainv[i] = 1.0 / R[static_cast<size_t>(i) * m + i];
+  double acc[2][kDcSolveMaxCols], lcur[2], lnext[2] = {0.0, 0.0};
+  MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+    const int r = tid + slot * nt;
+    MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) acc[slot][c] = (r == c0 + c && c < nc) ? 1.0 : 0.0;
+    lcur[slot] = (r > c0 && r < m) ? R[static_cast<size_t>(c0) * m + r] : 0.0;
+  }
   __syncthreads();
   for (int i = c0; i < m; ++i) {
-    if (tid < nc) { const double a = 1.0 / R[static_cast<size_t>(i) * m + i]; o[i * ld + tid] *= a; }
-    __syncthreads();
-    const double* Li = R + static_cast<size_t>(i) * m;
-    for (int r = i + 1 + tid; r < m; r += nt) {
-      const double l = Li[r];
-      for (int c = 0; c < nc; ++c) o[r * ld + c] -= o[i * ld + c] * l;
+    MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+      const int r = tid + slot * nt;
+      if (r == i) { const double a = ainv[i]; MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) { if (c < nc) { const double v = acc[slot][c] * a; acc[slot][c] = v; brow[(i & 1) * cols + c] = v; } } }
+      lnext[slot] = (i + 1 < m && r > i + 1 && r < m) ? R[static_cast<size_t>(i + 1) * m + r] : 0.0;
     }
     __syncthreads();
+    MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+      const int r = tid + slot * nt;
+      if (r > i && r < m) { MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) { if (c < nc) { const double pr = brow[(i & 1) * cols + c] * lcur[slot]; acc[slot][c] -= pr; } } }
+      lcur[slot] = lnext[slot];
+    }
   }
-  double* pr_ = o + static_cast<size_t>(m) * ld;                         // products L(r,i) o[r] of the current row, formed by all threads
+  MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+    const int r = tid + slot * nt;
+    if (r < m) { MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) { if (c < nc) o[r * ld + c] = acc[slot][c]; } }
+  }
+  __syncthreads();
+  const bool split = nt > 64;                                           // wavefront 0 walks the chains, the others form the next step's products
+  double lfirst = 0.0;                                                  // L(i+1, i): the factor of the chain's first term, requested a step ahead
   for (int i = m - 1; i >= 0; --i) {
-    const double* Li = R + static_cast<size_t>(i) * m;
-    const int rows = m - 1 - i;
-    for (int e = tid; e < rows * nc; e += nt) { const int r = i + 1 + e / nc, c = e % nc; pr_[r * ld + c] = Li[r] * o[r * ld + c]; }
-    __syncthreads();
-    if (tid < nc) {                                                      // the chain: eight products requested while the eight before them are added
+    const double* cur = (i & 1) ? prA : prB; double* nxt = (i & 1) ? prB : prA;
+    const double lf = lfirst;                                           // (of this step)
+    if (i >= 1) lfirst = R[static_cast<size_t>(i - 1) * m + i];          // (of the next one)
+    if (tid < nc) {
       double b = 0.0;
-      int r = i + 1;
+      if (i + 1 < m) { const double p = lf * o[(i + 1) * ld + tid]; b += p; }
+      int r = i + 2;
       double nx8[8];
-      if (r + 8 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = pr_[(r + q) * ld + tid]; }
+      if (r + 8 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = cur[(r + q) * ld + tid]; }
       for (; r + 8 <= m; r += 8) {
         double t8[8];
         MAS_UNROLL for (int q = 0; q < 8; ++q) t8[q] = nx8[q];
-        if (r + 16 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = pr_[(r + 8 + q) * ld + tid]; }
+        if (r + 16 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = cur[(r + 8 + q) * ld + tid]; }
         MAS_UNROLL for (int q = 0; q < 8; ++q) b += t8[q];
       }
-      for (; r < m; ++r) b += pr_[r * ld + tid];
-      o[i * ld + tid] = (o[i * ld + tid] - b) * (1.0 / Li[i]);
+      for (; r < m; ++r) b += cur[r * ld + tid];
+      o[i * ld + tid] = (o[i * ld + tid] - b) * ainv[i];
+    }
+    if (i >= 1 && (!split || tid >= 64)) {                              // products of step i - 1: rows r >= i + 1 (final), L(r, i - 1)
+      const double* Lp = R + static_cast<size_t>(i - 1) * m;
+      const int lanes = split ? nt - 64 : nt, me = split ? tid - 64 : tid;
+      for (int e = me; e < ((m - 1 - i) << cshift); e += lanes) {
+        const int r = i + 1 + (e >> cshift), c = e & (cols - 1);
+        if (c < nc) nxt[r * ld + c] = Lp[r] * o[r * ld + c];
+      }
     }
     __syncthreads();
   }
