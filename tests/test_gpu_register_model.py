@@ -64,7 +64,7 @@ def gpu_lib(product_lib):
 @pytest.fixture(scope="module")
 def user_single_track(gpu_lib):
     from multi_agent_solver_amd.batch import register_model
-    return register_model(USER_SINGLE_TRACK, "UserSingleTrack", lib=gpu_lib)          # ~1.5 minutes of hipcc
+    return register_model(USER_SINGLE_TRACK, "UserSingleTrack", lib=gpu_lib)          # about a minute of hipcc
 
 
 @pytest.mark.parametrize("strategy,outer", [("sequential", 3), ("trustregion", 3), ("linesearch", 2), ("centralized", 1), ("centralized_dense", 1)])
