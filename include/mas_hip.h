@@ -130,7 +130,7 @@ int mas_hip_model_dims(int model_id, int* nx, int* nu);
  *   struct_name     its name
  *   source_root     tree that holds multi_agent_solver_amd/csrc and include (NULL: the tree this library was built in)
  *   model_id        out: the id to put into mas_hip_problem_desc::model_id (>= 100)
- * The struct is compiled with the ROCm compiler of the machine (hipcc; about a minute: the host driver and every kernel template for
+ * The struct is compiled with the ROCm compiler of the machine (hipcc; ~1.5 minutes: the host driver and every kernel template for
  * this model, with the library's own options -- no contraction, IEEE division) into a plugin library, which is loaded into the
  * process.  Needs hipcc at run time; MAS_HIP_ERR_INVALID with the compiler's messages in mas_hip_last_error(NULL) when the source
  * does not compile.  Process-wide, thread-safe, not undone. */
