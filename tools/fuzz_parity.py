@@ -16,6 +16,7 @@ from oracle import oracle as O  # noqa: E402
 
 BIG = int(os.environ.get("FUZZ_BIG", "1"))      # agent-count multiplier (FUZZ_BIG=8: batches of thousands, slower oracle)
 ONLY = int(os.environ.get("FUZZ_MODEL", "0"))   # 1..6: that model only, with the large agent counts (e.g. 5: bicycle6 across the 16 / 32 / 64-lane backward forms)
+ONLY_STRATEGY = os.environ.get("FUZZ_STRATEGY", "")   # e.g. centralized_dense: that strategy only, with larger stacked problems
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
@@ -33,8 +34,12 @@ for c in range(cases):
         N, T = int(rng.integers(1, 4)), int(rng.integers(5, 40))
     if strategy == "centralized":
         N = min(N, 200 * min(BIG, 5))
+    if ONLY_STRATEGY:
+        strategy = ONLY_STRATEGY
     if strategy == "centralized_dense":
         N, T = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+        if ONLY_STRATEGY:                      # FUZZ_STRATEGY=centralized_dense: stacked problems of up to 240 states, held against the oracle's structured restatement
+            N, T = int(rng.integers(1, 41)), int(rng.integers(1, 41))
     if model == 5:
         T = int(rng.integers(1, 120))
     max_outer = int(rng.integers(1, 5))
@@ -62,7 +67,8 @@ for c in range(cases):
         s.set_initial_states(x0); s.set_controls(U0); s.initialize_problem()
         s.run(strategy, max_outer)
         e = s.solution(); st = s.stats()
-    o = O.solve_batch(model, x0, U0, T, DT[model], strategy=strategy, max_outer=max_outer, max_iterations=max_it, tolerance=tol)
+    o = O.solve_batch(model, x0, U0, T, DT[model], strategy=("centralized_dense_structured" if strategy == "centralized_dense" and N > 6 else strategy),
+                      max_outer=max_outer, max_iterations=max_it, tolerance=tol)
     eq = lambda a, b: np.array_equal(a, b, equal_nan=True)      # (pendulum with T = 1: its cost divides by T - 1 -> NaN on both sides)
     ok = (eq(e["cost"], o["cost"]) and eq(e["X"], o["X"]) and eq(e["U"], o["U"]) and
           e["iters"].tolist() == o["iters"].tolist() and st["reg_events"] == o["stats"]["reg_events"])
