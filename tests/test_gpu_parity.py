@@ -553,6 +553,19 @@ def test_fused_round_agrees_across_the_line_search_forms(gpu_lib, oracle, model,
     assert new["iters"][sample].tolist() == o["iters"].tolist()
 
 
+@pytest.mark.parametrize("model,N,T,dt,options", [("MODEL_LQR_IDENTITY", 200, 4, 0.1, {}), ("MODEL_LQR_IDENTITY", 200, 4, 0.1, {"dense_ladder_blocked": 0}),
+                                                 ("MODEL_LQR_IDENTITY", 256, 3, 0.1, {}), ("MODEL_BICYCLE6", 140, 3, 0.25, {})])
+def test_centralized_dense_wide_stacked_problems(gpu_lib, oracle, model, N, T, dt, options):
+    """the chip-wide literal solve at its limits: 800 and 1024 stacked controls (two rows of the factor per thread in the LLT kernels and in
+    LLT::solve, both ladder forms), 840 stacked states of the six-state model -- against the oracle's structured restatement"""
+    mid = getattr(oracle, model)
+    nx, _, _ = oracle.model_dims(mid)
+    rng = np.random.default_rng(2)
+    x0 = (oracle.lqr_x0(N) if model == "MODEL_LQR_IDENTITY" else oracle.bicycle6_x0(N)) + 0.1 * rng.standard_normal((N, nx))
+    e = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized_dense", max_iterations=3, options=options)
+    _same(e, oracle.solve_batch(mid, x0, None, T, dt, strategy="centralized_dense_structured", max_iterations=3))
+
+
 @pytest.mark.parametrize("N", [2, 8, 16, 32, 64])
 def test_both_centralised_readings_at_config2s_horizon(gpu_lib, oracle, N):
     """C2's horizon (H = 100): the reference's literal stacked solve on the device is bit-equal to the oracle's dense restatement (the plain
