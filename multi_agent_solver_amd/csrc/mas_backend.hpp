@@ -217,7 +217,8 @@ struct Backend {
   }
   template <class K, class... Args>
   void launch_kernel_lds(K kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args) {
-    if (lds_bytes > 64 * 1024) MAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    // (above 32 KB: dynamic + the kernel's static LDS may pass the 64-KB default together)
+    if (lds_bytes > 32 * 1024) MAS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     hipExtLaunchKernelGGL(kernel, grid, block, static_cast<uint32_t>(lds_bytes), cur, ev0, ev1, 0, args...);
     MAS_HIP_CHECK(hipGetLastError());
   }

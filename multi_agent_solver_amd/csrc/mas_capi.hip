@@ -108,6 +108,7 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
   if (!struct_source || !struct_name || !model_id) { g_create_error = "null argument"; return MAS_HIP_ERR_INVALID; }
   for (const char* c = struct_name; *c; ++c)
     if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9' && c != struct_name) || *c == '_')) { g_create_error = "struct_name is not an identifier"; return MAS_HIP_ERR_INVALID; }
+  if (source_root) for (const char* c = source_root; *c; ++c) if (*c == '\'' || *c == '\n') { g_create_error = "source_root must not contain quotes or line breaks"; return MAS_HIP_ERR_INVALID; }
   std::lock_guard<std::mutex> lock(g_register_mutex);
   // the headers: <root>/multi_agent_solver_amd/csrc and <root>/include; by default the tree this library was built in
   std::string root = source_root ? source_root : "";
@@ -138,8 +139,9 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
   dims(&rm.nx, &rm.nu);
   if (rm.nx < 1 || rm.nx > 8 || rm.nu < 1 || rm.nu > 8) { dlclose(lib); g_create_error = "NX and NU must lie in 1 .. 8"; return MAS_HIP_ERR_INVALID; }
   rm.library = lib; rm.name = struct_name;
-  mas::registered_models().push_back(rm);
-  *model_id = mas::kFirstRegisteredModel + static_cast<int>(mas::registered_models().size()) - 1;
+  const int id = mas::register_model_entry(rm);
+  if (id < 0) { dlclose(lib); g_create_error = "model registry full"; return MAS_HIP_ERR_RUNTIME; }
+  *model_id = id;
   std::remove(src.c_str()); std::remove(log.c_str());      // (model.so stays mapped; its directory entry is left for the process's lifetime)
   return MAS_HIP_OK;
 }

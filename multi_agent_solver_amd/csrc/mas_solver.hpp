@@ -11,6 +11,7 @@
 // line search -> select -> commit, and reads back one integer (agents still active).
 #pragma once
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <iostream>
@@ -958,14 +959,28 @@ std::unique_ptr<SolverBase> make_solver_ilp(const ProblemDesc& desc, void* exter
 // library whose factory is entered here; ids start at kFirstRegisteredModel
 constexpr int kFirstRegisteredModel = 100;
 struct RegisteredModel { int nx = 0, nu = 0; SolverBase* (*make)(const ProblemDesc*, void*) = nullptr; void* library = nullptr; std::string name; };
-inline std::vector<RegisteredModel>& registered_models() { static std::vector<RegisteredModel> models; return models; }
-inline const RegisteredModel* registered_model(int model_id) {
-  const auto& r = registered_models();
+constexpr int kMaxRegisteredModels = 256;
+// a fixed table filled front to back: an entry is complete before `count` (release) makes it visible, readers (acquire) never see a
+// table that moves -- handles may be created on other threads while a model is being registered
+struct ModelRegistry { RegisteredModel models[kMaxRegisteredModels]; std::atomic<int> count{0}; };
+inline ModelRegistry& model_registry() { static ModelRegistry r; return r; }
+inline bool registered_model(int model_id, RegisteredModel* out) {
+  ModelRegistry& r = model_registry();
   const int k = model_id - kFirstRegisteredModel;
-  return (k >= 0 && k < static_cast<int>(r.size())) ? &r[static_cast<size_t>(k)] : nullptr;
+  if (k < 0 || k >= r.count.load(std::memory_order_acquire)) return false;
+  *out = r.models[k];
+  return true;
+}
+inline int register_model_entry(const RegisteredModel& rm) {      // (callers serialise: mas_hip_register_model holds its mutex)
+  ModelRegistry& r = model_registry();
+  const int k = r.count.load(std::memory_order_relaxed);
+  if (k >= kMaxRegisteredModels) return -1;
+  r.models[k] = rm;
+  r.count.store(k + 1, std::memory_order_release);
+  return kFirstRegisteredModel + k;
 }
 inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* external_stream) {
-  if (const RegisteredModel* rm = registered_model(desc.model_id)) return std::unique_ptr<SolverBase>(rm->make(&desc, external_stream));
+  { RegisteredModel rm; if (registered_model(desc.model_id, &rm)) return std::unique_ptr<SolverBase>(rm.make(&desc, external_stream)); }
   switch (desc.model_id) {
     case 1: return std::make_unique<SolverImpl<SingleTrack>>(desc, external_stream);
     case 2: return make_solver_ilp(desc, external_stream);
@@ -981,7 +996,7 @@ inline std::unique_ptr<SolverBase> make_solver(const ProblemDesc& desc, void* ex
 inline bool model_dims(int model_id, int* nx, int* nu) {
   int a = 0, b = 0;
 #if !defined(MAS_TU_MODELS_ILP)
-  if (const RegisteredModel* rm = registered_model(model_id)) { if (nx) *nx = rm->nx; if (nu) *nu = rm->nu; return true; }
+  { RegisteredModel rm; if (registered_model(model_id, &rm)) { if (nx) *nx = rm.nx; if (nu) *nu = rm.nu; return true; } }
 #endif
   switch (model_id) {
     case 1: a = SingleTrack::NX; b = SingleTrack::NU; break;
