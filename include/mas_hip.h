@@ -187,7 +187,7 @@ int mas_hip_run_centralized(mas_hip_solver*);
  * alpha / termination / regularisation by construction.  4 (N nx)^2 evaluations of the N-agent cost per time step and a dense
  * (N nx) x (N nx) Riccati recursion; computed as chip-wide launches with exact re-use only (csrc/mas_dense_chip.hpp: the prefix of the
  * summed cost's own chain of additions, the exact zeros of the stacked A and B) up to 256 agents and 1024 stacked controls
- * (MAS_HIP_ERR_INVALID beyond): single-track, H = 100: 0.1 s at 16 agents, 0.4 s at 64, 4.3 s at BASELINE config 2's 256.  Bit-equal to
+ * (MAS_HIP_ERR_INVALID beyond): single-track, H = 100: 0.1 s at 16 agents, 0.4 s at 64, 2.7 s at BASELINE config 2's 256.  Bit-equal to
  * the CPU oracle's restatement.  mas_hip_set_option("dense_chip", 0) selects the one-workgroup form of rounds 2-3 (<= 64 agents, 56 s
  * there).  Precondition of the re-use: finite value function (a diverged solve may differ in WHICH non-finite values it holds).
  * Per-agent costs are the agents' own objectives of

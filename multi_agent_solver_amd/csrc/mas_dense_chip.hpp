@@ -525,7 +525,8 @@ static __global__ void __launch_bounds__(512) dc_ladder(DenseChipWs w, int m, in
 // panel: once panel p (columns pB .. pB+B-1) is final, EVERY entry to its right adds that panel's B terms, in j order, to its running value
 // (dc_llt_update: 64 x 64 tiles of the trailing triangle of all sixteen rungs, 4 x 4 entries per thread) -- the terms reach every entry
 // in the order of the serial loop -- and only the panel itself (dc_llt_panel: one workgroup per rung, thread = row, pivot / division /
-// next column's term, two barriers a column) is a chain.  m / B panel steps instead of m column steps: 3.4 -> 0.8 ms per 512 x 512 ladder.
+// next column's term, two barriers a column) is a chain.  m / B panel steps instead of m column steps (B = 32; 16 beyond 512 rows: the panel
+// lives in LDS).
 // The running sum of squares of row r (for its own pivot: x = M(r,r) - s, s from 0.0 in j order) is kept in SD by the panel kernel.
 constexpr int kDcBlock = 32;
 static __global__ void dc_llt_init(DenseChipWs w, int m) {
@@ -540,57 +541,58 @@ static __global__ void dc_llt_init(DenseChipWs w, int m) {
     if (q == 0) w.rung_state[rung] = 0;
   }
 }
-static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m, int p) {
-  __shared__ double sh_x[2], tri[kDcBlock * kDcBlock]; __shared__ int sh_fail;
+static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m, int p, int bw) {
+  extern __shared__ double dc_lds[];                                    // ap[bw][m]: the panel's columns (entry (r, k0 + q) at ap[q m + r])
+  __shared__ double sh_x[2], tri[kDcBlock * kDcBlock], diag[kDcBlock]; __shared__ int sh_fail;
   DenseChipState* S = w.S;
   const int rung = static_cast<int>(blockIdx.x);
   if (S->stop || w.rung_state[rung] != 0) return;
   const int tid = static_cast<int>(threadIdx.x), nt = static_cast<int>(blockDim.x);
   double* R = w.Rr + static_cast<size_t>(rung) * m * m; double* SD = w.SD + static_cast<size_t>(rung) * m;
-  const int k0 = p * kDcBlock, pw = min(kDcBlock, m - k0);
-  double a[2][kDcBlock], sq[2];
+  double* ap = dc_lds;
+  const int k0 = p * bw, pw = min(bw, m - k0);
+  double sq[2];
   MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
     const int r = tid + slot * nt;
     sq[slot] = (r < m) ? SD[r] : 0.0;
-    MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) a[slot][q] = (q < pw && r > k0 + q && r < m) ? R[static_cast<size_t>(k0 + q) * m + r] : 0.0;
+    if (r < m) for (int q = 0; q < pw; ++q) ap[q * m + r] = (r > k0 + q) ? R[static_cast<size_t>(k0 + q) * m + r] : 0.0;
   }
-  __shared__ double diag[kDcBlock];                                      // M(k,k) of the panel's columns, fetched ahead of the chain
-  if (tid < pw) diag[tid] = R[static_cast<size_t>(k0 + tid) * m + k0 + tid];
+  if (tid < pw) diag[tid] = R[static_cast<size_t>(k0 + tid) * m + k0 + tid];      // M(k,k) of the panel's columns, fetched ahead of the chain
   if (tid == 0) sh_fail = 0;
   __syncthreads();
+  // The column loop is a LOOP, the panel lives in LDS: unrolled over registers (the first form) its 32 x 31 / 2 update statements were 50 KB of
+  // code that every launch fetched cold -- 3 us a column, most of it instruction fetch.  Nothing inside the loop touches global memory.
   bool failed = false;
-  MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) {
+#pragma nounroll
+  for (int q = 0; q < pw; ++q) {
     const int k = k0 + q;
-    if (q < pw && !failed) {                                             // (uniform)
-      if (tid == k % nt) {
-        double x = diag[q];
-        if (k > 0) x = x - ((k / nt) ? sq[1] : sq[0]);
-        if (x <= 0.0) sh_fail = 1;                                      // (NaN pivots pass, like Eigen)
-        else { x = sqrt(x); diag[q] = x; sh_x[q & 1] = x; }
+    if (tid == k % nt) {
+      double x = diag[q];
+      if (k > 0) x = x - ((k / nt) ? sq[1] : sq[0]);
+      if (x <= 0.0) sh_fail = 1;                                        // (NaN pivots pass, like Eigen)
+      else { x = sqrt(x); diag[q] = x; sh_x[q & 1] = x; }
+    }
+    __syncthreads();
+    if (sh_fail) { failed = true; break; }                              // (uniform)
+    const double x = sh_x[q & 1];
+    double v[2] = {0.0, 0.0};
+    MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+      const int r = tid + slot * nt;
+      if (r > k && r < m) {
+        v[slot] = ap[q * m + r] / x;
+        ap[q * m + r] = v[slot];
+        sq[slot] += v[slot] * v[slot];
+        if (r < k0 + pw) tri[q * kDcBlock + (r - k0)] = -v[slot];       // [column][row of the panel]: -L(k0 + q2, k)
       }
-      __syncthreads();
-      if (sh_fail) failed = true;
-      if (!failed) {
-        const double x = sh_x[q & 1];
-        double v[2] = {0.0, 0.0};
-        MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
-          const int r = tid + slot * nt;
-          if (r > k && r < m) {
-            v[slot] = a[slot][q] / x;
-            a[slot][q] = v[slot];                                       // (the column's entries leave for memory behind the loop: a store in front of a barrier makes the barrier wait for it)
-            sq[slot] += v[slot] * v[slot];
-            if (r < k0 + kDcBlock) tri[q * kDcBlock + (r - k0)] = -v[slot];      // [column][row of the panel]: the next loop reads one column's entries side by side
-          }
-        }
-        __syncthreads();
-        MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
-          const int r = tid + slot * nt;
-          if (r > k && r < m) {
-            // every later column of the panel takes its next term -(L(k0+q2, k)) L(r, k); entries on or above the diagonal (k0 + q2 >= r) and
-            // beyond the panel's width are never read again, so nothing is tested here and the 31 LDS reads travel together
-            MAS_UNROLL for (int q2 = q + 1; q2 < kDcBlock; ++q2) { const double pr = tri[q * kDcBlock + q2] * v[slot]; a[slot][q2] += pr; }
-          }
-        }
+    }
+    __syncthreads();
+    MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
+      const int r = tid + slot * nt;
+      if (r > k && r < m) {
+        // every later column of the panel takes its next term (-L(k0 + q2, k)) L(r, k); entries on or above the diagonal (k0 + q2 >= r) are
+        // never read again, so nothing is tested here
+#pragma unroll 4
+        for (int q2 = q + 1; q2 < pw; ++q2) { const double pr = tri[q * kDcBlock + q2] * v[slot]; ap[q2 * m + r] += pr; }
       }
     }
   }
@@ -598,18 +600,20 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
   if (failed) { if (tid == 0) { w.rung_state[rung] = 1; __hip_atomic_fetch_or(&S->rung_failed, 1ull << rung, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
   MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
     const int r = tid + slot * nt;
-    if (r < m) SD[r] = sq[slot];
-    MAS_UNROLL for (int q = 0; q < kDcBlock; ++q) { if (q < pw && r > k0 + q && r < m) R[static_cast<size_t>(k0 + q) * m + r] = a[slot][q]; }
+    if (r < m) {
+      SD[r] = sq[slot];
+      for (int q = 0; q < pw; ++q) { if (r > k0 + q) R[static_cast<size_t>(k0 + q) * m + r] = ap[q * m + r]; }
+    }
   }
   if (tid < pw) R[static_cast<size_t>(k0 + tid) * m + k0 + tid] = diag[tid];
   if (k0 + pw >= m && tid == 0) { w.rung_state[rung] = 2; atomicMin(&S->rung_best, rung); }
 }
-static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m, int p) {
+static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m, int p, int bw) {
   __shared__ double Lr[kDcBlock][64 + 4], Lk[kDcBlock][64 + 4];
   const int rung = static_cast<int>(blockIdx.y);
   if (w.S->stop || w.rung_state[rung] != 0) return;
   double* R = w.Rr + static_cast<size_t>(rung) * m * m;
-  const int k0p = p * kDcBlock, c0 = k0p + kDcBlock;                     // the panel's first column; first column of the trailing part
+  const int k0p = p * bw, c0 = k0p + bw;                                 // the panel's first column; first column of the trailing part
   if (c0 >= m) return;
   const int nb = (m - c0 + 63) / 64;                                    // 64-wide blocks of the trailing part; tiles (ti >= tk)
   int tile = static_cast<int>(blockIdx.x), ti = 0;
@@ -618,7 +622,7 @@ static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m
   if (ti >= nb) return;
   const int r0 = c0 + 64 * ti, kk0 = c0 + 64 * tk;
   const int tid = static_cast<int>(threadIdx.x), tx = tid & 15, ty = tid >> 4;
-  for (int e = tid; e < kDcBlock * 64; e += 256) {
+  for (int e = tid; e < bw * 64; e += 256) {
     const int j = e >> 6, c = e & 63;
     Lr[j][c] = (r0 + c < m) ? R[static_cast<size_t>(k0p + j) * m + r0 + c] : 0.0;
     Lk[j][c] = (kk0 + c < m) ? -R[static_cast<size_t>(k0p + j) * m + kk0 + c] : 0.0;
@@ -626,7 +630,7 @@ static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m
   __syncthreads();
   double acc[4][4];
   MAS_UNROLL for (int b = 0; b < 4; ++b) { MAS_UNROLL for (int a = 0; a < 4; ++a) { const int r = r0 + tx * 4 + a, k = kk0 + ty * 4 + b; acc[a][b] = (r > k && r < m) ? R[static_cast<size_t>(k) * m + r] : 0.0; } }
-  for (int j = 0; j < kDcBlock; ++j) {
+  for (int j = 0; j < bw; ++j) {
     double lr[4], lk[4];
     MAS_UNROLL for (int a = 0; a < 4; ++a) lr[a] = Lr[j][tx * 4 + a];
     MAS_UNROLL for (int b = 0; b < 4; ++b) lk[b] = Lk[j][ty * 4 + b];
@@ -643,7 +647,10 @@ static __global__ void __launch_bounds__(256) dc_llt_update(DenseChipWs w, int m
 // Backward substitution: o[i] = (o[i] - sum_{r>i} L(r,i) o[r]) / L(i,i) with the sum from 0.0 over r ascending -- its FIRST term is the row
 // that has only just become final, so the sum is a serial chain by construction (m^2 / 2 dependent additions per column).  One lane per
 // column walks it; the products of step i - 1 (all but that first term) are formed by the OTHER wavefronts while the chain of step i runs.
-constexpr int kDcSolveMaxCols = 16;
+// workgroup barrier for data exchanged through LDS only: waits for this wavefront's LDS operations, not for its vector memory -- __syncthreads()
+// is also a fence for global memory, i.e. it drains every load a step has requested AHEAD for the next one (a memory round trip per barrier)
+__device__ __forceinline__ void dc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int kDcSolveMaxCols = 16, kDcSolvePasses = 12;
 static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int cshift) {
   extern __shared__ double dc_lds[];
   DenseChipState* S = w.S;
@@ -656,8 +663,12 @@ static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int
   const int c0 = static_cast<int>(blockIdx.x) * cols, nc = min(cols, m - c0);
   if (nc <= 0) return;
   double* o = dc_lds;                                                   // [m][ld] the columns' vectors
-  double* prA = o + static_cast<size_t>(m) * ld; double* prB = prA + static_cast<size_t>(m) * ld;      // products of the backward substitution, two steps
-  double* ainv = prB + static_cast<size_t>(m) * ld;                     // [m] 1 / L(i,i)
+  // products of the backward substitution, two steps: [column][row], columns pl doubles apart -- a column's terms are CONTIGUOUS, so the lane
+  // that adds them up reads two per LDS instruction at immediate offsets (the chain is a lone wavefront: it is bound by instructions per
+  // term, measured 5 -> 38 cycles per term with the terms a row apart); pl = m + 2 keeps the 8-16 columns of a read on distinct banks
+  const int pl = m + 2;
+  double* prA = o + static_cast<size_t>(m) * ld; double* prB = prA + static_cast<size_t>(cols) * pl;
+  double* ainv = prB + static_cast<size_t>(cols) * pl;                  // [m] 1 / L(i,i)
   double* brow = ainv + m;                                              // [2][cols] the scaled row of the current step
   for (int i = tid; i < m; i += nt) ainv[i] = 1.0 / R[static_cast<size_t>(i) * m + i];
   double acc[2][kDcSolveMaxCols], lcur[2], lnext[2] = {0.0, 0.0};
@@ -673,7 +684,7 @@ static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int
       if (r == i) { const double a = ainv[i]; MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) { if (c < nc) { const double v = acc[slot][c] * a; acc[slot][c] = v; brow[(i & 1) * cols + c] = v; } } }
       lnext[slot] = (i + 1 < m && r > i + 1 && r < m) ? R[static_cast<size_t>(i + 1) * m + r] : 0.0;
     }
-    __syncthreads();
+    dc_lds_barrier();
     MAS_UNROLL for (int slot = 0; slot < 2; ++slot) {
       const int r = tid + slot * nt;
       if (r > i && r < m) { MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) { if (c < nc) { const double pr = brow[(i & 1) * cols + c] * lcur[slot]; acc[slot][c] -= pr; } } }
@@ -684,8 +695,12 @@ static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int
     const int r = tid + slot * nt;
     if (r < m) { MAS_UNROLL for (int c = 0; c < kDcSolveMaxCols; ++c) { if (c < nc) o[r * ld + c] = acc[slot][c]; } }
   }
-  __syncthreads();
+  dc_lds_barrier();
   const bool split = nt > 64;                                           // wavefront 0 walks the chains, the others form the next step's products
+  const int lanes = split ? nt - 64 : nt, me = split ? tid - 64 : tid;
+  const int rpp = max(1, lanes >> cshift), passes = (m + rpp - 1) / rpp, my_r = me >> cshift, my_c = me & (cols - 1);      // rows per pass of the product lanes
+  double lreg[kDcSolvePasses];                                          // L(r, i - 1) of this lane's rows for the products formed in step i
+  MAS_UNROLL for (int k2 = 0; k2 < kDcSolvePasses; ++k2) { const int r = my_r + k2 * rpp; lreg[k2] = (m >= 2 && k2 < passes && r < m && me >= 0) ? R[static_cast<size_t>(m - 2) * m + r] : 0.0; }
   double lfirst = 0.0;                                                  // L(i+1, i): the factor of the chain's first term, requested a step ahead
   for (int i = m - 1; i >= 0; --i) {
     const double* cur = (i & 1) ? prA : prB; double* nxt = (i & 1) ? prB : prA;
@@ -694,28 +709,44 @@ static __global__ void __launch_bounds__(512) dc_solve(DenseChipWs w, int m, int
     if (tid < nc) {
       double b = 0.0;
       if (i + 1 < m) { const double p = lf * o[(i + 1) * ld + tid]; b += p; }
+      const double* col = cur + static_cast<size_t>(tid) * pl;
       int r = i + 2;
-      double nx8[8];
-      if (r + 8 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = cur[(r + q) * ld + tid]; }
-      for (; r + 8 <= m; r += 8) {
-        double t8[8];
-        MAS_UNROLL for (int q = 0; q < 8; ++q) t8[q] = nx8[q];
-        if (r + 16 <= m) { MAS_UNROLL for (int q = 0; q < 8; ++q) nx8[q] = cur[(r + 8 + q) * ld + tid]; }
-        MAS_UNROLL for (int q = 0; q < 8; ++q) b += t8[q];
+      if ((m & 1) == 0) {                                               // (16-byte aligned pairs)
+        if ((r & 1) && r < m) { b += col[r]; ++r; }
+        for (; r + 32 <= m; r += 32) {                                  // 32 terms requested at once (two register sets, nothing is copied), then added in order
+          double2 ta[8], tb[8];
+          MAS_UNROLL for (int q = 0; q < 8; ++q) ta[q] = *reinterpret_cast<const double2*>(col + r + 2 * q);
+          MAS_UNROLL for (int q = 0; q < 8; ++q) tb[q] = *reinterpret_cast<const double2*>(col + r + 16 + 2 * q);
+          MAS_UNROLL for (int q = 0; q < 8; ++q) { b += ta[q].x; b += ta[q].y; }
+          MAS_UNROLL for (int q = 0; q < 8; ++q) { b += tb[q].x; b += tb[q].y; }
+        }
+        for (; r + 8 <= m; r += 8) {
+          double2 t4[4];
+          MAS_UNROLL for (int q = 0; q < 4; ++q) t4[q] = *reinterpret_cast<const double2*>(col + r + 2 * q);
+          MAS_UNROLL for (int q = 0; q < 4; ++q) { b += t4[q].x; b += t4[q].y; }
+        }
       }
-      for (; r < m; ++r) b += cur[r * ld + tid];
+      for (; r < m; ++r) b += col[r];
       o[i * ld + tid] = (o[i * ld + tid] - b) * ainv[i];
     }
     if (i >= 1 && (!split || tid >= 64)) {                              // products of step i - 1: rows r >= i + 1 (final), L(r, i - 1)
-      const double* Lp = R + static_cast<size_t>(i - 1) * m;
-      const int lanes = split ? nt - 64 : nt, me = split ? tid - 64 : tid;
-      for (int e = me; e < ((m - 1 - i) << cshift); e += lanes) {
-        const int r = i + 1 + (e >> cshift), c = e & (cols - 1);
-        if (c < nc) nxt[r * ld + c] = Lp[r] * o[r * ld + c];
+      if (passes <= kDcSolvePasses) {                                   // every lane owns fixed rows; their factor entries were requested a step ago
+        MAS_UNROLL for (int k2 = 0; k2 < kDcSolvePasses; ++k2) {
+          const int r = my_r + k2 * rpp;
+          if (k2 < passes && r >= i + 1 && r < m && my_c < nc) nxt[static_cast<size_t>(my_c) * pl + r] = lreg[k2] * o[r * ld + my_c];
+          if (k2 < passes && i >= 2 && r >= i && r < m) lreg[k2] = R[static_cast<size_t>(i - 2) * m + r];      // for the products of the next step
+        }
+      } else {
+        const double* Lp = R + static_cast<size_t>(i - 1) * m;
+        for (int e = me; e < ((m - 1 - i) << cshift); e += lanes) {
+          const int r = i + 1 + (e >> cshift), c = e & (cols - 1);
+          if (c < nc) nxt[static_cast<size_t>(c) * pl + r] = Lp[r] * o[r * ld + c];
+        }
       }
     }
-    __syncthreads();
+    dc_lds_barrier();
   }
+  __syncthreads();
   for (int e = tid; e < m * nc; e += nt) { const int c = e / m, r = e % m; w.inv[static_cast<size_t>(c0 + c) * m + r] = o[r * ld + c]; }
 }
 

@@ -512,7 +512,7 @@ inline void initialize_agents(MultiAgentProblem& problem) {
 // ----------------------------------------------------------------------- strategies ------
 // strategies/centralized.hpp:10-39.  The reference stacks all agents into one OCP and finite-differences the SUMMED cost
 // (dense cross-agent Hessians): `Literal` is that solve on the device (mas_hip_run_centralized_dense, <= 256 agents: chip-wide
-// launches, 0.4 s at 64 agents and 4.3 s at 256 for H = 100); `Blocked` is the block-diagonal reading that scales
+// launches, 0.4 s at 64 agents and 2.7 s at 256 for H = 100); `Blocked` is the block-diagonal reading that scales
 // (mas_hip_run_centralized, <= 1024 agents, a millisecond at 256; a different number).  `Auto` takes the
 // literal solve -- the reference's own number -- up to 64 agents (the reference's example defaults to 10) and the reading that
 // scales beyond.
