@@ -50,6 +50,10 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert p["vs_det_oracle"] == "exact" and p["compared_agents"] == 512
     assert set(p["vs_libm_oracle"]) >= {"median_rel", "max_rel", "total_rel", "frac_le_1e-5", "north_star_tolerance_1e-5_met"}
     assert j["also_config2"]["parity"]["vs_det_oracle"] == "exact"
+    # round 4: BASELINE configs[1] also under the reference's LITERAL centralised algorithm (chip-wide launches), held against the oracle's committed vectors
+    lit = j["also_config2"]["literal_stacked_solve"]
+    assert lit["agents"] == 256 and lit["vs_oracle_structured_restatement"] == "exact" and lit["iterations"] == 8 and 0.0 < lit["seconds_per_solve"] < 60.0
+    assert lit["block_diagonal_vs_literal_total_rel"] > 0.0 and lit["unit"] == "agent-iterations/s"
     # round 3: the four-state models run two-kernel rounds; the roofline kernel is the fused linearise + Riccati kernel (sweep +
     # backward bytes of SURVEY 8(d)), and the sweep as a kernel of its own is measured in the same run with the five-kernel round
     r = j["roofline"]
