@@ -591,8 +591,14 @@ static __global__ void __launch_bounds__(512) dc_llt_panel(DenseChipWs w, int m,
       if (r > k && r < m) {
         // every later column of the panel takes its next term (-L(k0 + q2, k)) L(r, k); entries on or above the diagonal (k0 + q2 >= r) are
         // never read again, so nothing is tested here
-#pragma unroll 4
-        for (int q2 = q + 1; q2 < pw; ++q2) { const double pr = tri[q * kDcBlock + q2] * v[slot]; ap[q2 * m + r] += pr; }
+        // (eight columns at a time: their operands requested together, then the eight results stored -- an LDS round trip per chunk, not per column)
+        int q2 = q + 1;
+        for (; q2 + 8 <= pw; q2 += 8) {
+          double tq[8], aq[8];
+          MAS_UNROLL for (int u = 0; u < 8; ++u) { tq[u] = tri[q * kDcBlock + q2 + u]; aq[u] = ap[(q2 + u) * m + r]; }
+          MAS_UNROLL for (int u = 0; u < 8; ++u) { const double pr = tq[u] * v[slot]; ap[(q2 + u) * m + r] = aq[u] + pr; }
+        }
+        for (; q2 < pw; ++q2) { const double pr = tri[q * kDcBlock + q2] * v[slot]; ap[q2 * m + r] += pr; }
       }
     }
   }
