@@ -268,3 +268,26 @@ def test_dependency_levels_of_the_vehicle_models(hostcheck_lib):
     exe = os.path.join(ROOT, "tests", "hostcheck", "build", "levels_check")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "levels_check: 0 mismatches" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("strategy,okey,outer", [("sequential", "sequential", 3), ("trustregion", "trustregion", 3), ("linesearch", "linesearch", 2),
+                                                   ("centralized", "centralized", 1), ("single", "single", 1)])
+def test_user_defined_model_through_the_driver(hostcheck_lib, oracle, strategy, okey, outer):
+    """A workload of the kind mas_hip_register_model compiles at run time -- FdModel<Self, NX, NU> with the reference's three callbacks, every
+    derivative finite-differenced -- instantiated in the host emulation (tests/hostcheck/user_model_check.cpp): the single-track workload
+    written again must give the oracle's bits (cost, iterations, x_T, u_0 of every agent).  The GPU tier holds the same struct, compiled by
+    hipcc into a plugin, against the built-in model (tests/test_gpu_register_model.py)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "hostcheck", "build", "user_model_check")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    N, T = 6, 25
+    x0 = oracle.single_track_x0(N) + 0.03 * np.arange(N * 4).reshape(N, 4) / (N * 4)
+    r = subprocess.run([exe, str(N), str(T), strategy], input=" ".join(float(v).hex() for v in x0.ravel()), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    o = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK, x0, None, T, 0.5, strategy=okey, max_outer=outer)
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("agent ")]
+    assert len(lines) == N
+    for a, w in enumerate(lines):
+        assert float.fromhex(w[3]) == o["cost"][a] and int(w[5]) == int(o["iters"][a]), (a, w)
+        assert [float.fromhex(v) for v in w[7:11]] == o["X"][a, T].tolist()
+        assert [float.fromhex(v) for v in w[12:14]] == o["U"][a, 0].tolist()
