@@ -11,7 +11,11 @@
 #include <mutex>
 #include <new>
 #include <sstream>
+#include <algorithm>
+#include <vector>
+#include <dirent.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "mas_solver.hpp"
@@ -115,21 +119,43 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
   if (root.empty()) { const std::string lib = directory_of_this_library(); root = lib + "/../.."; }
   const std::string csrc = root + "/multi_agent_solver_amd/csrc", inc = root + "/include";
   if (!file_exists(csrc + "/mas_solver.hpp") || !file_exists(inc + "/mas_dettrig.h")) { g_create_error = "kernel headers not found under " + root + " (pass source_root)"; return MAS_HIP_ERR_INVALID; }
-  char dir_template[] = "/tmp/mas_model_XXXXXX";
-  const char* dir = mkdtemp(dir_template);
-  if (!dir) { g_create_error = "mkdtemp failed"; return MAS_HIP_ERR_RUNTIME; }
-  const std::string d = dir, src = d + "/model.hip", so = d + "/model.so", log = d + "/build.log";
-  {
-    std::ofstream f(src);
-    f << "// generated by mas_hip_register_model\n#include \"mas_solver.hpp\"\nnamespace mas {\n" << struct_source << "\n}  // namespace mas\n"
-      << "extern \"C\" mas::SolverBase* mas_plugin_make(const mas::ProblemDesc* desc, void* stream) { return new mas::SolverImpl<mas::" << struct_name << ">(*desc, stream); }\n"
-      << "extern \"C\" void mas_plugin_dims(int* nx, int* nu) { *nx = mas::" << struct_name << "::NX; *nu = mas::" << struct_name << "::NU; }\n";
+  // compiled models are kept: the key is a hash of the struct, its name and every header it is compiled against, so a process that registers
+  // the same workload again (every start of an application) loads the plugin instead of waiting a minute for the compiler
+  unsigned long long key = 1469598103934665603ull;
+  auto mix = [&](const std::string& bytes) { for (unsigned char c : bytes) { key ^= c; key *= 1099511628211ull; } key ^= 0xffu; key *= 1099511628211ull; };
+  mix(struct_source); mix(struct_name);
+  for (const std::string& hdir : {csrc, inc}) {
+    std::vector<std::string> names;
+    if (DIR* dp = opendir(hdir.c_str())) { while (dirent* e = readdir(dp)) { const std::string n = e->d_name; if (n.size() > 2 && n[0] != '.') names.push_back(n); } closedir(dp); }
+    std::sort(names.begin(), names.end());
+    for (const std::string& n : names) { if (n.find(".h") == std::string::npos && n.find(".inc") == std::string::npos) continue; mix(n); std::ifstream f(hdir + "/" + n, std::ios::binary); std::stringstream ss; ss << f.rdbuf(); mix(ss.str()); }
   }
-  const char* env_cc = std::getenv("HIPCC");
-  const std::string cc = env_cc ? env_cc : (file_exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc");
-  // the options libmas_hip.so itself is built with (__graft_entry__.py): nothing is contracted, IEEE division and square root
-  const std::string cmd = "'" + cc + "' --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -shared -I'" + csrc + "' -I'" + inc + "' '" + src + "' -o '" + so + "' > '" + log + "' 2>&1";
-  if (std::system(cmd.c_str()) != 0 || !file_exists(so)) { g_create_error = "the model did not compile (" + log + "):\n" + tail_of_file(log, 2000); return MAS_HIP_ERR_INVALID; }
+  const char* env_cache = std::getenv("MAS_HIP_MODEL_CACHE");
+  const std::string cache_dir = env_cache ? env_cache : ("/tmp/mas_hip_models_" + std::to_string(static_cast<unsigned long>(getuid())));
+  (void)mkdir(cache_dir.c_str(), 0700);
+  char keyhex[32]; std::snprintf(keyhex, sizeof keyhex, "%016llx", key);
+  const std::string cached = cache_dir + "/" + struct_name + "_" + keyhex + ".so";
+  std::string so = cached;
+  if (!file_exists(cached)) {
+    char dir_template[] = "/tmp/mas_model_XXXXXX";
+    const char* dir = mkdtemp(dir_template);
+    if (!dir) { g_create_error = "mkdtemp failed"; return MAS_HIP_ERR_RUNTIME; }
+    const std::string d = dir, src = d + "/model.hip", log = d + "/build.log";
+    so = d + "/model.so";
+    {
+      std::ofstream f(src);
+      f << "// generated by mas_hip_register_model\n#include \"mas_solver.hpp\"\nnamespace mas {\n" << struct_source << "\n}  // namespace mas\n"
+        << "extern \"C\" mas::SolverBase* mas_plugin_make(const mas::ProblemDesc* desc, void* stream) { return new mas::SolverImpl<mas::" << struct_name << ">(*desc, stream); }\n"
+        << "extern \"C\" void mas_plugin_dims(int* nx, int* nu) { *nx = mas::" << struct_name << "::NX; *nu = mas::" << struct_name << "::NU; }\n";
+    }
+    const char* env_cc = std::getenv("HIPCC");
+    const std::string cc = env_cc ? env_cc : (file_exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc");
+    // the options libmas_hip.so itself is built with (__graft_entry__.py): nothing is contracted, IEEE division and square root
+    const std::string cmd = "'" + cc + "' --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -shared -I'" + csrc + "' -I'" + inc + "' '" + src + "' -o '" + so + "' > '" + log + "' 2>&1";
+    if (std::system(cmd.c_str()) != 0 || !file_exists(so)) { g_create_error = "the model did not compile (" + log + "):\n" + tail_of_file(log, 2000); return MAS_HIP_ERR_INVALID; }
+    std::remove(src.c_str()); std::remove(log.c_str());
+    if (std::rename(so.c_str(), cached.c_str()) == 0) { so = cached; (void)rmdir(d.c_str()); }      // (a rename inside one file system; otherwise the plugin is loaded from where it was built)
+  }
   void* lib = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
   if (!lib) { g_create_error = std::string("dlopen of the compiled model failed: ") + dlerror(); return MAS_HIP_ERR_RUNTIME; }
   mas::RegisteredModel rm;
@@ -142,7 +168,6 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
   const int id = mas::register_model_entry(rm);
   if (id < 0) { dlclose(lib); g_create_error = "model registry full"; return MAS_HIP_ERR_RUNTIME; }
   *model_id = id;
-  std::remove(src.c_str()); std::remove(log.c_str());      // (model.so stays mapped; its directory entry is left for the process's lifetime)
   return MAS_HIP_OK;
 }
 #else

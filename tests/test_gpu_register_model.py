@@ -101,6 +101,14 @@ def test_a_workload_the_library_has_never_seen(gpu_lib):
         assert np.abs(e["X"][a].T - r["X"]).max() <= 5e-2
 
 
+def test_the_second_registration_loads_the_cached_plugin(gpu_lib, user_single_track):
+    import time
+    from multi_agent_solver_amd.batch import register_model
+    t0 = time.time()
+    again = register_model(USER_SINGLE_TRACK, "UserSingleTrack", lib=gpu_lib)
+    assert again != user_single_track and time.time() - t0 < 5.0          # (a new id for the same plugin; the compiler did not run)
+
+
 def test_a_model_that_does_not_compile_is_refused_with_the_compilers_words(gpu_lib):
     from multi_agent_solver_amd._capi import MasHipError, ERR_INVALID
     from multi_agent_solver_amd.batch import register_model
