@@ -123,7 +123,9 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
   // the same workload again (every start of an application) loads the plugin instead of waiting a minute for the compiler
   unsigned long long key = 1469598103934665603ull;
   auto mix = [&](const std::string& bytes) { for (unsigned char c : bytes) { key ^= c; key *= 1099511628211ull; } key ^= 0xffu; key *= 1099511628211ull; };
-  mix(struct_source); mix(struct_name);
+  const char* env_cc = std::getenv("HIPCC");
+  const std::string cc = env_cc ? env_cc : (file_exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc");
+  mix(struct_source); mix(struct_name); mix(cc); mix("--offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off");
   for (const std::string& hdir : {csrc, inc}) {
     std::vector<std::string> names;
     if (DIR* dp = opendir(hdir.c_str())) { while (dirent* e = readdir(dp)) { const std::string n = e->d_name; if (n.size() > 2 && n[0] != '.') names.push_back(n); } closedir(dp); }
@@ -148,8 +150,6 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
         << "extern \"C\" mas::SolverBase* mas_plugin_make(const mas::ProblemDesc* desc, void* stream) { return new mas::SolverImpl<mas::" << struct_name << ">(*desc, stream); }\n"
         << "extern \"C\" void mas_plugin_dims(int* nx, int* nu) { *nx = mas::" << struct_name << "::NX; *nu = mas::" << struct_name << "::NU; }\n";
     }
-    const char* env_cc = std::getenv("HIPCC");
-    const std::string cc = env_cc ? env_cc : (file_exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc");
     // the options libmas_hip.so itself is built with (__graft_entry__.py): nothing is contracted, IEEE division and square root
     const std::string cmd = "'" + cc + "' --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -shared -I'" + csrc + "' -I'" + inc + "' '" + src + "' -o '" + so + "' > '" + log + "' 2>&1";
     if (std::system(cmd.c_str()) != 0 || !file_exists(so)) { g_create_error = "the model did not compile (" + log + "):\n" + tail_of_file(log, 2000); return MAS_HIP_ERR_INVALID; }
