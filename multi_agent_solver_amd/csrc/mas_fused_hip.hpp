@@ -264,7 +264,12 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
 
     // ---- pass 1 (ilqr.hpp:115-116 and the first factors of :117-119)
     double qx_i, qu_own;
-    {
+    constexpr bool kIdentity = M::kIdentityJacobians && !kMerged && NU == NX;      // A = B = I: every product of passes 1 and 2 is V (or v_x) itself
+    static_assert(!kIdentity || !Src::kRequestLate, "identity Jacobians: tiles come from the analytic source");
+    if constexpr (kIdentity) {
+      qx_i = c.lx + vxi;                                                // q_x = l_x + A^T v_x,  q_u = l_u + B^T v_x: lane (i, j) holds v_x(i), and iu == i
+      qu_own = c.lu + vxi;
+    } else {
       const double Vc[NX] = {quad_bcast<0>(Vown), quad_bcast<1>(Vown), quad_bcast<2>(Vown), quad_bcast<3>(Vown)};   // V(k, j)
       const double vxk[NX] = {row_bcast<0>(vxi), row_bcast<1>(vxi), row_bcast<2>(vxi), row_bcast<3>(vxi)};         // v_x(k)
       double s;
@@ -279,10 +284,20 @@ __device__ __forceinline__ void fused_backward_wave(const Dims& d, const ModelPa
       s = sum_terms<NX>([&](int k) { return Bi[k] * vxk[k]; });
       qu_own = c.lu + s;
     }
-    wave_sync();
+    if constexpr (!kIdentity) wave_sync();
     // ---- pass 2 (second factors of ilqr.hpp:117-119)
     double quu[NU * NU], qu[NU], quxj[NU], Lfac[NU * NU], ninv[NU * NU], kf[NU], qxx_own;
-    {
+    if constexpr (kIdentity) {
+      // q_xx = l_xx + (A^T V) A,  q_ux = l_ux + (B^T V) A,  q_uu = l_uu + (B^T V) B  with A = B = I: entry (i, j) of each is l + V(i, j), this lane's own
+      qxx_own = c.lxx + Vown;
+      T[oQxx + lane] = qxx_own;
+      const double qux_own = c.lux + Vown;
+      const double quu_own = c.luu + Vown;
+      T[w_qux] = qux_own;
+      row_gather_block_at<NU, 0>(quu_own, quu, std::make_integer_sequence<int, NU * NU>{});
+      quad_gather(qux_own, quxj, std::make_integer_sequence<int, NU>{});
+      row_gather_first(qu_own, qu, std::make_integer_sequence<int, NU>{});
+    } else {
       double ra[NX], rb[NX];
       MAS_UNROLL for (int k = 0; k < NX; ++k) { ra[k] = T[oAtV + i * 4 + k]; rb[k] = T[r_row2 + k]; }
       // the next step's tile is requested HERE, behind the operand reads of pass 2 (an LDS queue serves one wavefront's

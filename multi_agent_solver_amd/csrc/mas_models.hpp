@@ -36,6 +36,11 @@ struct NoConstraints {
   // so an open-loop rollout can be evaluated level by level, all time steps of a level side by side (mas_kernel_levels.hpp)
   static constexpr int kRolloutLevels = 0;
   MAS_HD static constexpr int state_level(int) { return 0; }
+  // true: the model's analytic Jacobians are A = I, B = I at every point (NU == NX).  A product sum with a column of the identity is one factor
+  // times 1 plus terms (+0.0) * v = +-0.0, i.e. the other factor's VALUE for finite operands, so A^T V, (A^T V) A, B^T V ... are V itself and a
+  // kernel may skip the sums (the fused recursion does: mas_fused_hip.hpp; the other forms and the oracle form them, the results are held
+  // against each other bit for bit)
+  static constexpr bool kIdentityJacobians = false;
   MAS_HD static void equality(const double*, const double*, double*, const ModelParams&) {}
   MAS_HD static void inequality(const double*, const double*, double*, const ModelParams&) {}
 };
@@ -110,6 +115,7 @@ struct SingleTrack : NoConstraints {
 
 struct LqrIdentity : NoConstraints {
   static constexpr int NX = 4, NU = 4;
+  static constexpr bool kIdentityJacobians = true;      // examples/multi_agent_lqr.cpp:35-41: A = B = I
   using Ctl = NoCtl;
   MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
   MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl&, double* d, const ModelParams& P) { dynamics(x, u, d, P); }
