@@ -1290,8 +1290,29 @@ static double b6_stage(const mas_ocp* o, const double* s, const double* c, size_
 static void stl_eq(const mas_ocp* o, const double* x, const double* u, double* out) { (void)x; out[0] = u[0] - o->params[9] * u[1]; }
 static void stl_ineq(const mas_ocp* o, const double* x, const double* u, double* out) { (void)u; out[0] = x[3] - o->params[8]; out[1] = -x[3]; }
 
+/* ---- external models (ids >= 100): the three callbacks of an OCP (types.hpp:21-50) as plain C functions, e.g. a user-defined workload of the
+ * product (mas_hip_register_model) compiled for the CPU by oracle.register_model().  Every derivative hook stays empty => finite differences. */
+#define MAS_EXTERNAL_FIRST 100
+#define MAS_EXTERNAL_MAX 64
+typedef struct { int nx, nu, has_bounds; double lb[8], ub[8]; mas_ext_dynamics_fn dyn; mas_ext_stage_fn stage; mas_ext_terminal_fn term; } ext_model;
+static ext_model g_ext[MAS_EXTERNAL_MAX];
+static int g_ext_count = 0;
+int mas_oracle_register_external_model(int nx, int nu, mas_ext_dynamics_fn dyn, mas_ext_stage_fn stage, mas_ext_terminal_fn term,
+                                       const double* lb, const double* ub) {
+  if (g_ext_count >= MAS_EXTERNAL_MAX || nx < 1 || nx > 16 || nu < 1 || nu > 8 || !dyn || !stage || !term) return -1;
+  ext_model* e = &g_ext[g_ext_count];
+  e->nx = nx; e->nu = nu; e->dyn = dyn; e->stage = stage; e->term = term; e->has_bounds = (lb && ub);
+  if (e->has_bounds) for (int i = 0; i < nu; ++i) { e->lb[i] = lb[i]; e->ub[i] = ub[i]; }
+  return MAS_EXTERNAL_FIRST + g_ext_count++;
+}
+static const ext_model* ext_of(int model_id) { const int k = model_id - MAS_EXTERNAL_FIRST; return (k >= 0 && k < g_ext_count) ? &g_ext[k] : NULL; }
+static void ext_dynamics(const mas_ocp* o, const double* x, const double* u, double* d) { ext_of(o->model_id)->dyn(x, u, d, o->params); }
+static double ext_stage(const mas_ocp* o, const double* x, const double* u, size_t t) { return ext_of(o->model_id)->stage(x, u, (int)t, o->params); }
+static double ext_terminal(const mas_ocp* o, const double* x) { return ext_of(o->model_id)->term(x, o->params); }
+
 int mas_model_dims(int model_id, int* nx, int* nu, int* n_params) {
   int a = 0, b = 0, c = 0;
+  if (ext_of(model_id)) { if (nx) *nx = ext_of(model_id)->nx; if (nu) *nu = ext_of(model_id)->nu; if (n_params) *n_params = 16; return 0; }
   switch (model_id) {
     case MAS_MODEL_SINGLE_TRACK: a = 4; b = 2; c = 7; break;
     case MAS_MODEL_LQR_IDENTITY: a = 4; b = 4; c = 0; break;
@@ -1331,6 +1352,11 @@ mas_ocp* mas_model_make_ocp(int model_id, int T, double dt, const double* x0, co
   if (params) memcpy(o->params, params, sizeof(double) * 16); else mas_model_default_params(model_id, T, o->params);
   memcpy(o->initial_state, x0, sizeof(double) * nx);
   o->terminal_cost = zero_terminal;
+  if (ext_of(model_id)) {
+    const ext_model* e = ext_of(model_id);
+    o->dynamics = ext_dynamics; o->stage_cost = ext_stage; o->terminal_cost = ext_terminal;
+    if (e->has_bounds) mas_ocp_set_input_bounds(o, e->lb, e->ub);
+  }
   switch (model_id) {
     case MAS_MODEL_SINGLE_TRACK: {
       o->dynamics = st_dynamics; o->stage_cost = st_stage;

@@ -222,6 +222,14 @@ enum {
                                         steering/acceleration coupling) to exercise the augmented-Lagrangian branch */
 };
 
+/* external models (ids >= 100): dynamics / stage cost / terminal cost as plain C functions over the problem's 16 constants; every derivative is
+ * finite-differenced.  oracle.register_model() compiles a user-defined workload of the product for the CPU and enters it here. */
+typedef void   (*mas_ext_dynamics_fn)(const double* x, const double* u, double* dxdt, const double* params16);
+typedef double (*mas_ext_stage_fn)(const double* x, const double* u, int t, const double* params16);
+typedef double (*mas_ext_terminal_fn)(const double* x, const double* params16);
+int mas_oracle_register_external_model(int nx, int nu, mas_ext_dynamics_fn, mas_ext_stage_fn, mas_ext_terminal_fn,
+                                       const double* lower_bounds /* NULL: none */, const double* upper_bounds);
+
 /* Build an initialised OCP of a registered model.  x0: nx values.  U0: NULL => zeros.
  * params: NULL => the example's constants.  Bounds come from the model definition. */
 mas_ocp* mas_model_make_ocp(int model_id, int T, double dt, const double* x0, const double* U0, const double* params, size_t id);

@@ -96,6 +96,54 @@ def default_params(model_id: int, T: int) -> np.ndarray:
     return p
 
 
+_EXT_KEEP = []      # loaded shims and their callbacks stay alive
+
+
+def register_model(struct_source: str, struct_name: str) -> int:
+    """A user-defined workload of the product (a struct deriving from mas::FdModel<Self, NX, NU>, the source mas_hip_register_model takes)
+    compiled for the CPU: g++ with the oracle's own options over multi_agent_solver_amd/csrc/mas_models.hpp in its host form (MAS_HD = inline,
+    `/` for div_by, sin / cos / tan from include/mas_dettrig.h), its three callbacks entered as an external model.  Returns the oracle's
+    model id (>= 100) for solve_batch.  Test infrastructure: what it checks is the PRODUCT's treatment of the same struct."""
+    import hashlib
+    import tempfile
+    root = os.path.dirname(_HERE)
+    tag = hashlib.sha256((struct_source + struct_name).encode()).hexdigest()[:16]
+    d = os.path.join(tempfile.gettempdir(), f"mas_oracle_models_{os.getuid()}")
+    os.makedirs(d, exist_ok=True)
+    so, src = os.path.join(d, f"{struct_name}_{tag}.so"), os.path.join(d, f"{struct_name}_{tag}.cpp")
+    if not os.path.exists(so):
+        with open(src, "w") as f:
+            f.write(f"""#define MAS_HOST_EMULATION 1
+#include <cstring>
+#include "{root}/multi_agent_solver_amd/csrc/mas_models.hpp"
+namespace mas {{
+{struct_source}
+}}
+using M = mas::{struct_name};
+static mas::ModelParams pack(const double* p) {{ mas::ModelParams P; std::memcpy(P.p, p, sizeof(P.p)); return P; }}
+extern "C" void ext_dyn(const double* x, const double* u, double* d, const double* p) {{ M::dynamics(x, u, d, pack(p)); }}
+extern "C" double ext_stage(const double* x, const double* u, int t, const double* p) {{ return M::stage_cost(x, u, t, pack(p)); }}
+extern "C" double ext_term(const double* x, const double* p) {{ return M::terminal_cost(x, pack(p)); }}
+extern "C" int ext_info(int* nx, int* nu, double* lb, double* ub) {{ *nx = M::NX; *nu = M::NU; M::default_bounds(lb, ub); return M::kDefaultBounds ? 1 : 0; }}
+""")
+        fma = ["-mfma"] if any(" fma " in l + " " for l in open("/proc/cpuinfo") if l.startswith("flags")) else []
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", *fma, "-fPIC", "-shared", src, "-o", so])
+    shim = C.CDLL(so)
+    nx, nu = C.c_int(), C.c_int()
+    lb, ub = (C.c_double * 8)(), (C.c_double * 8)()
+    shim.ext_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    bounded = shim.ext_info(C.byref(nx), C.byref(nu), lb, ub)
+    f = lib().mas_oracle_register_external_model
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    mid = f(nx.value, nu.value, C.cast(shim.ext_dyn, C.c_void_p), C.cast(shim.ext_stage, C.c_void_p), C.cast(shim.ext_term, C.c_void_p),
+            lb if bounded else None, ub if bounded else None)
+    if mid < 0:
+        raise RuntimeError("the oracle's external-model table is full")
+    _EXT_KEEP.append(shim)
+    return mid
+
+
 def set_trig_mode(mode: str) -> None:
     """'libm': platform sin/cos/tan, as a glibc-linked reference binary calls them (default).
     'det': include/mas_dettrig.h, the bit-reproducible implementation the HIP path uses."""

@@ -7,7 +7,9 @@ compiled against the kernel templates at run time -- no rebuild of libmas_hip.so
    arithmetic per evaluation, other kernel forms.
 2. A workload the library has never seen (a cart with quadratic drag: two states, one control) against the SECOND restatement of the
    reference's solve, oracle/ilqr_numpy.py, which takes Python callbacks like the reference takes std::function: finite-difference-noise
-   tolerance, as in tests/test_oracle_numpy_crosscheck.py.
+   tolerance, as in tests/test_oracle_numpy_crosscheck.py -- and against the C oracle solving the SAME struct compiled for the CPU
+   (oracle.register_model): every bit.  A second unseen workload (trigonometry, input bounds, a time-dependent stage cost) the same way
+   under every strategy.
 3. A struct that does not compile: MAS_HIP_ERR_INVALID with the compiler's message."""
 import math
 
@@ -52,6 +54,29 @@ struct DragCart : FdModel<DragCart, 2, 1> {
 };
 """
 
+WHEELED_ARM = r"""
+struct WheeledArm : FdModel<WheeledArm, 5, 2> {                 // a unicycle carrying a joint: position, heading, speed, joint angle
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -1.0; ub[0] = 1.0; lb[1] = -0.7; ub[1] = 0.7; }
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    d[0] = x[3] * mas_dt_cos(x[2]);
+    d[1] = x[3] * mas_dt_sin(x[2]);
+    d[2] = x[3] * u[1];
+    d[3] = u[0] - P.p[3] * x[3];
+    d[4] = u[1] * mas_dt_cos(x[4]) - P.p[4] * mas_dt_sin(x[4]);
+  }
+  MAS_HD static double stage_cost(const double* x, const double* u, int t, const ModelParams& P) {
+    const double ex = x[0] - P.p[0], ey = x[1] - P.p[1], ej = x[4] - P.p[2];
+    const double w = t < 12 ? 1.0 : 2.0;
+    return w * (ex * ex + ey * ey) + 0.5 * ej * ej + 0.05 * u[0] * u[0] + 0.05 * u[1] * u[1];
+  }
+  MAS_HD static double terminal_cost(const double* x, const ModelParams& P) {
+    const double ex = x[0] - P.p[0], ey = x[1] - P.p[1];
+    return P.p[5] * (ex * ex + ey * ey) + x[3] * x[3];
+  }
+};
+"""
+
 SINGLE_TRACK_PARAMS = [20.0, 5.0, 1.0, 1.0, 0.001, 0.001, 2.5] + [0.0] * 9
 
 
@@ -83,7 +108,7 @@ def test_single_track_rewritten_as_a_user_model(gpu_lib, oracle, user_single_tra
     assert mine["iters"].tolist() == o["iters"].tolist()
 
 
-def test_a_workload_the_library_has_never_seen(gpu_lib):
+def test_a_workload_the_library_has_never_seen(gpu_lib, oracle):
     from multi_agent_solver_amd.batch import register_model
     from oracle import ilqr_numpy as inp
     mid = register_model(DRAG_CART, "DragCart", lib=gpu_lib)
@@ -91,6 +116,11 @@ def test_a_workload_the_library_has_never_seen(gpu_lib):
     params = np.array([drag, target] + [0.0] * 14)
     x0 = np.array([[0.0, 0.0], [0.5, -0.2], [-1.0, 1.0]])
     e = run_batch(gpu_lib, mid, x0, None, T, dt, "single", params=params, no_input_bounds=True)
+    # the same struct compiled for the CPU and solved by the C oracle: every bit
+    c = oracle.solve_batch(oracle.register_model(DRAG_CART, "DragCart"), x0, None, T, dt, strategy="single", params=params)
+    for key in ("cost", "X", "U"):
+        assert np.array_equal(e[key], c[key]), key
+    assert e["iters"].tolist() == c["iters"].tolist()
     for a in range(x0.shape[0]):
         p = inp.Problem(lambda x, u: np.array([x[1], u[0] - drag * x[1] * abs(x[1])]),
                         lambda x, u, t: (x[0] - target) ** 2 + 0.1 * x[1] * x[1] + 0.01 * u[0] * u[0],
@@ -99,6 +129,25 @@ def test_a_workload_the_library_has_never_seen(gpu_lib):
         assert abs(e["cost"][a] - r["cost"]) <= 5e-3 * abs(r["cost"]), (a, e["cost"][a], r["cost"])         # two FD solves: noise-level agreement
         assert abs(int(e["iters"][a]) - r["iterations"]) <= 1
         assert np.abs(e["X"][a].T - r["X"]).max() <= 5e-2
+
+
+@pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 3), ("trustregion", 3), ("linesearch", 2), ("centralized", 1), ("centralized_dense", 1)])
+def test_an_unseen_workload_with_trigonometry_and_bounds_under_every_strategy(gpu_lib, oracle, strategy, outer):
+    """Neither side has this model built in: the product compiles the struct with hipcc against the kernel templates, the oracle compiles the
+    same text with g++ against the models header in its host form -- bit-equal results, as for the built-in workloads."""
+    from multi_agent_solver_amd.batch import register_model
+    mid, oid = register_model(WHEELED_ARM, "WheeledArm", lib=gpu_lib), oracle.register_model(WHEELED_ARM, "WheeledArm")
+    N, T = (5, 10) if strategy == "centralized_dense" else (40, 24)
+    rng = np.random.default_rng(17)
+    x0 = np.column_stack([rng.uniform(-2, 2, N), rng.uniform(-2, 2, N), rng.uniform(-math.pi, math.pi, N), rng.uniform(0, 1, N), rng.uniform(-0.5, 0.5, N)])
+    params = np.array([1.5, -0.5, 0.8, 0.05, 0.02, 4.0] + [0.0] * 10)
+    e = run_batch(gpu_lib, mid, x0, None, T, 0.2, strategy, max_outer=outer, params=params)
+    c = oracle.solve_batch(oid, x0, None, T, 0.2, strategy=strategy, max_outer=outer, params=params)
+    for key in ("cost", "X", "U"):
+        assert np.array_equal(e[key], c[key]), key
+    assert e["iters"].tolist() == c["iters"].tolist()
+    # (the block-diagonal centralised merit is summed agent-major on the GPU and step-major in the oracle: DESIGN.md section 3)
+    assert abs(e["total_cost"] - c["total_cost"]) <= (1e-12 * abs(c["total_cost"]) if strategy == "centralized" else 0.0)
 
 
 def test_the_second_registration_loads_the_cached_plugin(gpu_lib, user_single_track):
