@@ -11,7 +11,7 @@ rows = []
 for f in glob.glob("gpurun_out/bylaunch_$W/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = ("fused" if "linearise_riccati" in n else "sweep" if "sweep" in n else "backward" if "backward_" in n else
+        k = ("fused" if "linearise_riccati" in n else "prologue" if "round_prologue" in n else "trust" if ("trust_" in n or "Trust" in n) else "sweep" if "sweep" in n else "backward" if "backward_" in n else
              "forward" if ("ForwardBody" in n or "forward_quad" in n) else "commit" if "Commit" in n else "select" if "SelectBody" in n else
              "rollout" if "rollout" in n.lower() else "other")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
