@@ -1294,13 +1294,14 @@ static void stl_ineq(const mas_ocp* o, const double* x, const double* u, double*
  * product (mas_hip_register_model) compiled for the CPU by oracle.register_model().  Every derivative hook stays empty => finite differences. */
 #define MAS_EXTERNAL_FIRST 100
 #define MAS_EXTERNAL_MAX 64
-typedef struct { int nx, nu, has_bounds; double lb[8], ub[8]; mas_ext_dynamics_fn dyn; mas_ext_stage_fn stage; mas_ext_terminal_fn term; } ext_model;
+typedef struct { int nx, nu, has_bounds; double lb[8], ub[8]; mas_ext_dynamics_fn dyn; mas_ext_stage_fn stage; mas_ext_terminal_fn term; mas_ext_hooks hooks; } ext_model;
 static ext_model g_ext[MAS_EXTERNAL_MAX];
 static int g_ext_count = 0;
 int mas_oracle_register_external_model(int nx, int nu, mas_ext_dynamics_fn dyn, mas_ext_stage_fn stage, mas_ext_terminal_fn term,
                                        const double* lb, const double* ub) {
   if (g_ext_count >= MAS_EXTERNAL_MAX || nx < 1 || nx > 16 || nu < 1 || nu > 8 || !dyn || !stage || !term) return -1;
   ext_model* e = &g_ext[g_ext_count];
+  memset(&e->hooks, 0, sizeof(e->hooks));
   e->nx = nx; e->nu = nu; e->dyn = dyn; e->stage = stage; e->term = term; e->has_bounds = (lb && ub);
   if (e->has_bounds) for (int i = 0; i < nu; ++i) { e->lb[i] = lb[i]; e->ub[i] = ub[i]; }
   return MAS_EXTERNAL_FIRST + g_ext_count++;
@@ -1309,6 +1310,22 @@ static const ext_model* ext_of(int model_id) { const int k = model_id - MAS_EXTE
 static void ext_dynamics(const mas_ocp* o, const double* x, const double* u, double* d) { ext_of(o->model_id)->dyn(x, u, d, o->params); }
 static double ext_stage(const mas_ocp* o, const double* x, const double* u, size_t t) { return ext_of(o->model_id)->stage(x, u, (int)t, o->params); }
 static double ext_terminal(const mas_ocp* o, const double* x) { return ext_of(o->model_id)->term(x, o->params); }
+/* the derivative hooks an external model provides (types.hpp:30-50); the others stay empty => finite differences (ocp.hpp:117-135) */
+int mas_oracle_external_set_hooks(int model_id, const mas_ext_hooks* hooks) {
+  const int k = model_id - MAS_EXTERNAL_FIRST;
+  if (k < 0 || k >= g_ext_count || !hooks) return -1;
+  g_ext[k].hooks = *hooks;
+  return 0;
+}
+static void ext_A(const mas_ocp* o, const double* x, const double* u, double* out) { ext_of(o->model_id)->hooks.A(x, u, out, o->params); }
+static void ext_B(const mas_ocp* o, const double* x, const double* u, double* out) { ext_of(o->model_id)->hooks.B(x, u, out, o->params); }
+static void ext_lx(const mas_ocp* o, const double* x, const double* u, size_t t, double* out) { ext_of(o->model_id)->hooks.lx(x, u, (int)t, out, o->params); }
+static void ext_lu(const mas_ocp* o, const double* x, const double* u, size_t t, double* out) { ext_of(o->model_id)->hooks.lu(x, u, (int)t, out, o->params); }
+static void ext_lxx(const mas_ocp* o, const double* x, const double* u, size_t t, double* out) { ext_of(o->model_id)->hooks.lxx(x, u, (int)t, out, o->params); }
+static void ext_luu(const mas_ocp* o, const double* x, const double* u, size_t t, double* out) { ext_of(o->model_id)->hooks.luu(x, u, (int)t, out, o->params); }
+static void ext_lux(const mas_ocp* o, const double* x, const double* u, size_t t, double* out) { ext_of(o->model_id)->hooks.lux(x, u, (int)t, out, o->params); }
+static void ext_tg(const mas_ocp* o, const double* x, double* out) { ext_of(o->model_id)->hooks.term_grad(x, out, o->params); }
+static void ext_th(const mas_ocp* o, const double* x, double* out) { ext_of(o->model_id)->hooks.term_hess(x, out, o->params); }
 
 int mas_model_dims(int model_id, int* nx, int* nu, int* n_params) {
   int a = 0, b = 0, c = 0;
@@ -1355,6 +1372,14 @@ mas_ocp* mas_model_make_ocp(int model_id, int T, double dt, const double* x0, co
   if (ext_of(model_id)) {
     const ext_model* e = ext_of(model_id);
     o->dynamics = ext_dynamics; o->stage_cost = ext_stage; o->terminal_cost = ext_terminal;
+    if (e->hooks.A) o->dynamics_state_jacobian = ext_A;
+    if (e->hooks.B) o->dynamics_control_jacobian = ext_B;
+    if (e->hooks.lx) o->cost_state_gradient = ext_lx;
+    if (e->hooks.lu) o->cost_control_gradient = ext_lu;
+    if (e->hooks.lxx) o->cost_state_hessian = ext_lxx;
+    if (e->hooks.luu) o->cost_control_hessian = ext_luu;
+    if (e->hooks.lux) o->cost_cross_term = ext_lux;
+    if (e->hooks.term_grad && e->hooks.term_hess) { o->terminal_cost_gradient = ext_tg; o->terminal_cost_hessian = ext_th; }
     if (e->has_bounds) mas_ocp_set_input_bounds(o, e->lb, e->ub);
   }
   switch (model_id) {

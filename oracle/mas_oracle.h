@@ -229,6 +229,13 @@ typedef double (*mas_ext_stage_fn)(const double* x, const double* u, int t, cons
 typedef double (*mas_ext_terminal_fn)(const double* x, const double* params16);
 int mas_oracle_register_external_model(int nx, int nu, mas_ext_dynamics_fn, mas_ext_stage_fn, mas_ext_terminal_fn,
                                        const double* lower_bounds /* NULL: none */, const double* upper_bounds);
+/* optional analytic derivative hooks of an external model (types.hpp:30-50; column-major matrices as everywhere here): a NULL entry
+ * stays finite-differenced.  term_grad and term_hess come as a pair, like the product's kAnalyticTerm. */
+typedef void (*mas_ext_xu_fn)(const double* x, const double* u, double* out, const double* params16);
+typedef void (*mas_ext_xut_fn)(const double* x, const double* u, int t, double* out, const double* params16);
+typedef void (*mas_ext_x_fn)(const double* x, double* out, const double* params16);
+typedef struct { mas_ext_xu_fn A, B; mas_ext_xut_fn lx, lu, lxx, luu, lux; mas_ext_x_fn term_grad, term_hess; } mas_ext_hooks;
+int mas_oracle_external_set_hooks(int model_id, const mas_ext_hooks* hooks);
 
 /* Build an initialised OCP of a registered model.  x0: nx values.  U0: NULL => zeros.
  * params: NULL => the example's constants.  Bounds come from the model definition. */

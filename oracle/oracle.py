@@ -102,12 +102,14 @@ _EXT_KEEP = []      # loaded shims and their callbacks stay alive
 def register_model(struct_source: str, struct_name: str) -> int:
     """A user-defined workload of the product (a struct deriving from mas::FdModel<Self, NX, NU>, the source mas_hip_register_model takes)
     compiled for the CPU: g++ with the oracle's own options over multi_agent_solver_amd/csrc/mas_models.hpp in its host form (MAS_HD = inline,
-    `/` for div_by, sin / cos / tan from include/mas_dettrig.h), its three callbacks entered as an external model.  Returns the oracle's
+    `/` for div_by, sin / cos / tan from include/mas_dettrig.h), its three callbacks -- and the analytic derivative hooks it declares
+    (kAnalyticA ... kAnalyticTerm, types.hpp:30-50) -- entered as an external model.  Returns the oracle's
     model id (>= 100) for solve_batch.  Test infrastructure: what it checks is the PRODUCT's treatment of the same struct."""
     import hashlib
     import tempfile
     root = os.path.dirname(_HERE)
-    tag = hashlib.sha256((struct_source + struct_name).encode()).hexdigest()[:16]
+    headers = b"".join(open(os.path.join(root, q), "rb").read() for q in ("multi_agent_solver_amd/csrc/mas_models.hpp", "multi_agent_solver_amd/csrc/mas_platform.hpp", "include/mas_dettrig.h"))
+    tag = hashlib.sha256(b"shim v3" + (struct_source + struct_name).encode() + headers).hexdigest()[:16]
     d = os.path.join(tempfile.gettempdir(), f"mas_oracle_models_{os.getuid()}")
     os.makedirs(d, exist_ok=True)
     so, src = os.path.join(d, f"{struct_name}_{tag}.so"), os.path.join(d, f"{struct_name}_{tag}.cpp")
@@ -125,6 +127,30 @@ extern "C" void ext_dyn(const double* x, const double* u, double* d, const doubl
 extern "C" double ext_stage(const double* x, const double* u, int t, const double* p) {{ return M::stage_cost(x, u, t, pack(p)); }}
 extern "C" double ext_term(const double* x, const double* p) {{ return M::terminal_cost(x, pack(p)); }}
 extern "C" int ext_info(int* nx, int* nu, double* lb, double* ub) {{ *nx = M::NX; *nu = M::NU; M::default_bounds(lb, ub); return M::kDefaultBounds ? 1 : 0; }}
+// the derivative hooks the struct provides (kAnalytic* = true): bit k of ext_hooks_mask() <-> entry k of the table handed to the oracle
+// (templates, so that a hook the struct does not have is never named)
+template <class Q> void hA(const double* x, const double* u, double* o, const double* p) {{ if constexpr (Q::kAnalyticA) Q::A(x, u, o, pack(p)); }}
+template <class Q> void hB(const double* x, const double* u, double* o, const double* p) {{ if constexpr (Q::kAnalyticB) Q::B(x, u, o, pack(p)); }}
+template <class Q> void hlx(const double* x, const double* u, int t, double* o, const double* p) {{ if constexpr (Q::kAnalyticLx) Q::lx(x, u, t, o, pack(p)); }}
+template <class Q> void hlu(const double* x, const double* u, int t, double* o, const double* p) {{ if constexpr (Q::kAnalyticLu) Q::lu(x, u, t, o, pack(p)); }}
+template <class Q> void hlxx(const double* x, const double* u, int t, double* o, const double* p) {{ if constexpr (Q::kAnalyticLxx) Q::lxx(x, u, t, o, pack(p)); }}
+template <class Q> void hluu(const double* x, const double* u, int t, double* o, const double* p) {{ if constexpr (Q::kAnalyticLuu) Q::luu(x, u, t, o, pack(p)); }}
+template <class Q> void hlux(const double* x, const double* u, int t, double* o, const double* p) {{ if constexpr (Q::kAnalyticLux) Q::lux(x, u, t, o, pack(p)); }}
+template <class Q> void htg(const double* x, double* o, const double* p) {{ if constexpr (Q::kAnalyticTerm) Q::term_grad(x, o, pack(p)); }}
+template <class Q> void hth(const double* x, double* o, const double* p) {{ if constexpr (Q::kAnalyticTerm) Q::term_hess(x, o, pack(p)); }}
+extern "C" void ext_A(const double* x, const double* u, double* o, const double* p) {{ hA<M>(x, u, o, p); }}
+extern "C" void ext_B(const double* x, const double* u, double* o, const double* p) {{ hB<M>(x, u, o, p); }}
+extern "C" void ext_lx(const double* x, const double* u, int t, double* o, const double* p) {{ hlx<M>(x, u, t, o, p); }}
+extern "C" void ext_lu(const double* x, const double* u, int t, double* o, const double* p) {{ hlu<M>(x, u, t, o, p); }}
+extern "C" void ext_lxx(const double* x, const double* u, int t, double* o, const double* p) {{ hlxx<M>(x, u, t, o, p); }}
+extern "C" void ext_luu(const double* x, const double* u, int t, double* o, const double* p) {{ hluu<M>(x, u, t, o, p); }}
+extern "C" void ext_lux(const double* x, const double* u, int t, double* o, const double* p) {{ hlux<M>(x, u, t, o, p); }}
+extern "C" void ext_tg(const double* x, double* o, const double* p) {{ htg<M>(x, o, p); }}
+extern "C" void ext_th(const double* x, double* o, const double* p) {{ hth<M>(x, o, p); }}
+extern "C" int ext_hooks_mask() {{
+  return (M::kAnalyticA ? 1 : 0) | (M::kAnalyticB ? 2 : 0) | (M::kAnalyticLx ? 4 : 0) | (M::kAnalyticLu ? 8 : 0) | (M::kAnalyticLxx ? 16 : 0) |
+         (M::kAnalyticLuu ? 32 : 0) | (M::kAnalyticLux ? 64 : 0) | (M::kAnalyticTerm ? 128 + 256 : 0);
+}}
 """)
         fma = ["-mfma"] if any(" fma " in l + " " for l in open("/proc/cpuinfo") if l.startswith("flags")) else []
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", *fma, "-fPIC", "-shared", src, "-o", so])
@@ -140,6 +166,15 @@ extern "C" int ext_info(int* nx, int* nu, double* lb, double* ub) {{ *nx = M::NX
             lb if bounded else None, ub if bounded else None)
     if mid < 0:
         raise RuntimeError("the oracle's external-model table is full")
+    mask = shim.ext_hooks_mask()
+    if mask:
+        names = ("ext_A", "ext_B", "ext_lx", "ext_lu", "ext_lxx", "ext_luu", "ext_lux", "ext_tg", "ext_th")
+        table = (C.c_void_p * 9)(*[C.cast(getattr(shim, n), C.c_void_p) if (mask >> k) & 1 else None for k, n in enumerate(names)])
+        h = lib().mas_oracle_external_set_hooks
+        h.restype = C.c_int
+        h.argtypes = [C.c_int, C.c_void_p]
+        if h(mid, C.cast(table, C.c_void_p)) != 0:
+            raise RuntimeError("mas_oracle_external_set_hooks failed")
     _EXT_KEEP.append(shim)
     return mid
 

@@ -150,6 +150,27 @@ def test_an_unseen_workload_with_trigonometry_and_bounds_under_every_strategy(gp
     assert abs(e["total_cost"] - c["total_cost"]) <= (1e-12 * abs(c["total_cost"]) if strategy == "centralized" else 0.0)
 
 
+@pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 2), ("trustregion", 3)])
+def test_a_user_model_with_analytic_derivative_hooks(gpu_lib, oracle, strategy, outer):
+    """The reference's optional derivative callbacks (types.hpp:30-50; ocp.hpp:117-135 finite-differences only the hooks left empty): a user
+    struct declares kAnalyticA ... and provides A / B / lx / lu / lxx / luu.  The lane-following workload written that way gives the bits of the
+    built-in model 4 and of the oracle (which takes the same hooks from the same struct: oracle.register_model)."""
+    from multi_agent_solver_amd.batch import register_model
+    from test_oracle_external_models import USER_LANE
+    mid, oid = register_model(USER_LANE, "UserLane", lib=gpu_lib), oracle.register_model(USER_LANE, "UserLane")
+    N, T = 90, 40
+    rng = np.random.default_rng(4)
+    x0 = np.column_stack([np.zeros(N), rng.uniform(-1.5, 1.5, N), rng.uniform(-0.3, 0.3, N), rng.uniform(2.0, 8.0, N)])
+    params = oracle.default_params(oracle.MODEL_SINGLE_TRACK_LANE, T)
+    mine = run_batch(gpu_lib, mid, x0, None, T, 0.1, strategy, max_outer=outer, params=params)
+    builtin = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK_LANE, x0, None, T, 0.1, strategy, max_outer=outer)
+    c = oracle.solve_batch(oid, x0, None, T, 0.1, strategy=strategy, max_outer=outer, params=params)
+    for key in ("cost", "X", "U"):
+        assert np.array_equal(mine[key], builtin[key]) and np.array_equal(mine[key], c[key]), key
+    assert mine["iters"].tolist() == builtin["iters"].tolist() == c["iters"].tolist()
+    assert mine["stats"]["reg_events"] == builtin["stats"]["reg_events"]
+
+
 def test_the_second_registration_loads_the_cached_plugin(gpu_lib, user_single_track):
     import time
     from multi_agent_solver_amd.batch import register_model

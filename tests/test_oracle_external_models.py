@@ -38,3 +38,54 @@ def test_an_external_model_without_a_twin_against_the_numpy_restatement(oracle):
         assert abs(c["cost"][a] - r["cost"]) <= 5e-3 * abs(r["cost"])
         assert abs(int(c["iters"][a]) - r["iterations"]) <= 1
         assert np.abs(c["X"][a].T - r["X"]).max() <= 5e-2
+
+
+# the lane-following workload (examples/single_track_ocp.cpp:14-116) as a user struct WITH the derivative hooks its example wires: analytic A, B,
+# l_x, l_u, l_xx, l_uu (models/single_track_model.hpp:49-82, single_track_ocp.cpp:62-94); the cross term and the terminal derivatives stay FD
+USER_LANE = r"""
+struct UserLane : FdModel<UserLane, 4, 2> {
+  static constexpr bool kAnalyticA = true, kAnalyticB = true, kAnalyticLx = true, kAnalyticLu = true, kAnalyticLxx = true, kAnalyticLuu = true;
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = -0.7; lb[1] = -1.0; ub[0] = 0.7; ub[1] = 1.0; }
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    const double psi = x[2], v = x[3], L = P.p[6];
+    d[0] = v * mas_dt_cos(psi); d[1] = v * mas_dt_sin(psi); d[2] = (v * mas_dt_tan(u[0])) / L; d[3] = u[1];
+  }
+  MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
+    const double lane_error = s[1], speed_error = s[3] - P.p[0];
+    return P.p[1] * (lane_error * lane_error) + P.p[2] * (speed_error * speed_error) + P.p[3] * (c[0] * c[0]) + P.p[4] * (c[1] * c[1]);
+  }
+  MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
+  MAS_HD static void A(const double* x, const double* u, double* M, const ModelParams& P) {
+    const double psi = x[2], v = x[3], L = P.p[6];
+    for (int i = 0; i < 16; ++i) M[i] = 0.0;
+    M[2 * 4 + 0] = -v * mas_dt_sin(psi); M[3 * 4 + 0] = mas_dt_cos(psi);
+    M[2 * 4 + 1] = v * mas_dt_cos(psi);  M[3 * 4 + 1] = mas_dt_sin(psi);
+    M[3 * 4 + 2] = mas_dt_tan(u[0]) / L;
+  }
+  MAS_HD static void B(const double* x, const double* u, double* M, const ModelParams& P) {
+    for (int i = 0; i < 8; ++i) M[i] = 0.0;
+    M[0 * 4 + 2] = x[3] / (P.p[6] * mas_dt_cos(u[0]) * mas_dt_cos(u[0]));
+    M[1 * 4 + 3] = 1.0;
+  }
+  MAS_HD static void lx(const double* x, const double*, int, double* g, const ModelParams& P) { g[0] = 0.0; g[1] = 2.0 * P.p[1] * x[1]; g[2] = 0.0; g[3] = 2.0 * P.p[2] * (x[3] - P.p[0]); }
+  MAS_HD static void lu(const double*, const double* u, int, double* g, const ModelParams& P) { g[0] = 2.0 * P.p[3] * u[0]; g[1] = 2.0 * P.p[4] * u[1]; }
+  MAS_HD static void lxx(const double*, const double*, int, double* H, const ModelParams& P) { for (int i = 0; i < 16; ++i) H[i] = 0.0; H[1 * 4 + 1] = 2.0 * P.p[1]; H[3 * 4 + 3] = 2.0 * P.p[2]; }
+  MAS_HD static void luu(const double*, const double*, int, double* H, const ModelParams& P) { H[0] = 2.0 * P.p[3]; H[1] = 0.0; H[2] = 0.0; H[3] = 2.0 * P.p[4]; }
+};
+"""
+
+
+@pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 2), ("trustregion", 3)])
+def test_an_external_model_with_analytic_hooks_is_the_built_in_lane_following_model(oracle, strategy, outer):
+    """The derivative hooks of an external model (kAnalytic* of the struct -> mas_oracle_external_set_hooks) take the place of the finite
+    differences exactly where the built-in lane-following model has them (ocp.hpp:117-135: FD only for hooks left empty)."""
+    mid = oracle.register_model(USER_LANE, "UserLane")
+    N, T = 7, 30
+    rng = np.random.default_rng(4)
+    x0 = np.column_stack([np.zeros(N), rng.uniform(-1.5, 1.5, N), rng.uniform(-0.3, 0.3, N), rng.uniform(2.0, 8.0, N)])
+    params = oracle.default_params(oracle.MODEL_SINGLE_TRACK_LANE, T)
+    b = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK_LANE, x0, None, T, 0.1, strategy=strategy, max_outer=outer)
+    a = oracle.solve_batch(mid, x0, None, T, 0.1, strategy=strategy, max_outer=outer, params=params)
+    for key in ("cost", "X", "U", "iters"):
+        assert np.array_equal(a[key], b[key]), key
