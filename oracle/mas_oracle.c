@@ -1294,7 +1294,8 @@ static void stl_ineq(const mas_ocp* o, const double* x, const double* u, double*
  * product (mas_hip_register_model) compiled for the CPU by oracle.register_model().  Every derivative hook stays empty => finite differences. */
 #define MAS_EXTERNAL_FIRST 100
 #define MAS_EXTERNAL_MAX 64
-typedef struct { int nx, nu, has_bounds; double lb[8], ub[8]; mas_ext_dynamics_fn dyn; mas_ext_stage_fn stage; mas_ext_terminal_fn term; mas_ext_hooks hooks; } ext_model;
+typedef struct { int nx, nu, has_bounds; double lb[8], ub[8]; mas_ext_dynamics_fn dyn; mas_ext_stage_fn stage; mas_ext_terminal_fn term; mas_ext_hooks hooks;
+                 int neq, nin; mas_ext_xu_fn eq, in; } ext_model;
 static ext_model g_ext[MAS_EXTERNAL_MAX];
 static int g_ext_count = 0;
 int mas_oracle_register_external_model(int nx, int nu, mas_ext_dynamics_fn dyn, mas_ext_stage_fn stage, mas_ext_terminal_fn term,
@@ -1302,6 +1303,7 @@ int mas_oracle_register_external_model(int nx, int nu, mas_ext_dynamics_fn dyn, 
   if (g_ext_count >= MAS_EXTERNAL_MAX || nx < 1 || nx > 16 || nu < 1 || nu > 8 || !dyn || !stage || !term) return -1;
   ext_model* e = &g_ext[g_ext_count];
   memset(&e->hooks, 0, sizeof(e->hooks));
+  e->neq = e->nin = 0; e->eq = e->in = NULL;
   e->nx = nx; e->nu = nu; e->dyn = dyn; e->stage = stage; e->term = term; e->has_bounds = (lb && ub);
   if (e->has_bounds) for (int i = 0; i < nu; ++i) { e->lb[i] = lb[i]; e->ub[i] = ub[i]; }
   return MAS_EXTERNAL_FIRST + g_ext_count++;
@@ -1317,6 +1319,15 @@ int mas_oracle_external_set_hooks(int model_id, const mas_ext_hooks* hooks) {
   g_ext[k].hooks = *hooks;
   return 0;
 }
+/* function constraints h(x,u) = 0 (neq rows), g(x,u) <= 0 (nin rows) of an external model (ocp.hpp:61-68); their Jacobians stay FD (ocp.hpp:137-171) */
+int mas_oracle_external_set_constraints(int model_id, int neq, mas_ext_xu_fn equality, int nin, mas_ext_xu_fn inequality) {
+  const int k = model_id - MAS_EXTERNAL_FIRST;
+  if (k < 0 || k >= g_ext_count || neq < 0 || nin < 0 || (neq > 0 && !equality) || (nin > 0 && !inequality)) return -1;
+  g_ext[k].neq = neq; g_ext[k].eq = equality; g_ext[k].nin = nin; g_ext[k].in = inequality;
+  return 0;
+}
+static void ext_eq(const mas_ocp* o, const double* x, const double* u, double* out) { ext_of(o->model_id)->eq(x, u, out, o->params); }
+static void ext_in(const mas_ocp* o, const double* x, const double* u, double* out) { ext_of(o->model_id)->in(x, u, out, o->params); }
 static void ext_A(const mas_ocp* o, const double* x, const double* u, double* out) { ext_of(o->model_id)->hooks.A(x, u, out, o->params); }
 static void ext_B(const mas_ocp* o, const double* x, const double* u, double* out) { ext_of(o->model_id)->hooks.B(x, u, out, o->params); }
 static void ext_lx(const mas_ocp* o, const double* x, const double* u, size_t t, double* out) { ext_of(o->model_id)->hooks.lx(x, u, (int)t, out, o->params); }
@@ -1379,6 +1390,8 @@ mas_ocp* mas_model_make_ocp(int model_id, int T, double dt, const double* x0, co
     if (e->hooks.lxx) o->cost_state_hessian = ext_lxx;
     if (e->hooks.luu) o->cost_control_hessian = ext_luu;
     if (e->hooks.lux) o->cost_cross_term = ext_lux;
+    if (e->neq > 0) { o->equality_constraints = ext_eq; o->eq_dim = e->neq; }
+    if (e->nin > 0) { o->inequality_constraints = ext_in; o->ineq_dim = e->nin; }
     if (e->hooks.term_grad && e->hooks.term_hess) { o->terminal_cost_gradient = ext_tg; o->terminal_cost_hessian = ext_th; }
     if (e->has_bounds) mas_ocp_set_input_bounds(o, e->lb, e->ub);
   }

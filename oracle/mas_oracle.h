@@ -236,6 +236,8 @@ typedef void (*mas_ext_xut_fn)(const double* x, const double* u, int t, double* 
 typedef void (*mas_ext_x_fn)(const double* x, double* out, const double* params16);
 typedef struct { mas_ext_xu_fn A, B; mas_ext_xut_fn lx, lu, lxx, luu, lux; mas_ext_x_fn term_grad, term_hess; } mas_ext_hooks;
 int mas_oracle_external_set_hooks(int model_id, const mas_ext_hooks* hooks);
+/* optional function constraints h(x,u) = 0, g(x,u) <= 0 (ocp.hpp:61-68) */
+int mas_oracle_external_set_constraints(int model_id, int neq, mas_ext_xu_fn equality, int nin, mas_ext_xu_fn inequality);
 
 /* Build an initialised OCP of a registered model.  x0: nx values.  U0: NULL => zeros.
  * params: NULL => the example's constants.  Bounds come from the model definition. */

@@ -109,7 +109,7 @@ def register_model(struct_source: str, struct_name: str) -> int:
     import tempfile
     root = os.path.dirname(_HERE)
     headers = b"".join(open(os.path.join(root, q), "rb").read() for q in ("multi_agent_solver_amd/csrc/mas_models.hpp", "multi_agent_solver_amd/csrc/mas_platform.hpp", "include/mas_dettrig.h"))
-    tag = hashlib.sha256(b"shim v3" + (struct_source + struct_name).encode() + headers).hexdigest()[:16]
+    tag = hashlib.sha256(b"shim v4" + (struct_source + struct_name).encode() + headers).hexdigest()[:16]
     d = os.path.join(tempfile.gettempdir(), f"mas_oracle_models_{os.getuid()}")
     os.makedirs(d, exist_ok=True)
     so, src = os.path.join(d, f"{struct_name}_{tag}.so"), os.path.join(d, f"{struct_name}_{tag}.cpp")
@@ -147,6 +147,9 @@ extern "C" void ext_luu(const double* x, const double* u, int t, double* o, cons
 extern "C" void ext_lux(const double* x, const double* u, int t, double* o, const double* p) {{ hlux<M>(x, u, t, o, p); }}
 extern "C" void ext_tg(const double* x, double* o, const double* p) {{ htg<M>(x, o, p); }}
 extern "C" void ext_th(const double* x, double* o, const double* p) {{ hth<M>(x, o, p); }}
+extern "C" void ext_eq(const double* x, const double* u, double* o, const double* p) {{ M::equality(x, u, o, pack(p)); }}
+extern "C" void ext_in(const double* x, const double* u, double* o, const double* p) {{ M::inequality(x, u, o, pack(p)); }}
+extern "C" void ext_constraint_dims(int* neq, int* nin) {{ *neq = M::NEQ; *nin = M::NIN; }}
 extern "C" int ext_hooks_mask() {{
   return (M::kAnalyticA ? 1 : 0) | (M::kAnalyticB ? 2 : 0) | (M::kAnalyticLx ? 4 : 0) | (M::kAnalyticLu ? 8 : 0) | (M::kAnalyticLxx ? 16 : 0) |
          (M::kAnalyticLuu ? 32 : 0) | (M::kAnalyticLux ? 64 : 0) | (M::kAnalyticTerm ? 128 + 256 : 0);
@@ -166,6 +169,14 @@ extern "C" int ext_hooks_mask() {{
             lb if bounded else None, ub if bounded else None)
     if mid < 0:
         raise RuntimeError("the oracle's external-model table is full")
+    neq, nin = C.c_int(), C.c_int()
+    shim.ext_constraint_dims(C.byref(neq), C.byref(nin))
+    if neq.value or nin.value:
+        g = lib().mas_oracle_external_set_constraints
+        g.restype = C.c_int
+        g.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        if g(mid, neq.value, C.cast(shim.ext_eq, C.c_void_p), nin.value, C.cast(shim.ext_in, C.c_void_p)) != 0:
+            raise RuntimeError("mas_oracle_external_set_constraints failed")
     mask = shim.ext_hooks_mask()
     if mask:
         names = ("ext_A", "ext_B", "ext_lx", "ext_lu", "ext_lxx", "ext_luu", "ext_lux", "ext_tg", "ext_th")

@@ -171,6 +171,25 @@ def test_a_user_model_with_analytic_derivative_hooks(gpu_lib, oracle, strategy, 
     assert mine["stats"]["reg_events"] == builtin["stats"]["reg_events"]
 
 
+@pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 2)])
+def test_a_user_model_with_function_constraints(gpu_lib, oracle, strategy, outer):
+    """h(x, u) = 0 and g(x, u) <= 0 of a user workload (ocp.hpp:61-68: NEQ / NIN + equality() / inequality() of the struct) through the
+    augmented-Lagrangian branch (ilqr.hpp:236-260): the constrained test workload written as a user struct gives the bits of the built-in
+    model 6 and of the oracle (same struct, oracle.register_model -> mas_oracle_external_set_constraints)."""
+    from multi_agent_solver_amd.batch import register_model
+    from test_oracle_external_models import USER_LIMITED
+    mid, oid = register_model(USER_LIMITED, "UserLimited", lib=gpu_lib), oracle.register_model(USER_LIMITED, "UserLimited")
+    N, T = 70, 30
+    x0 = oracle.single_track_x0(N)
+    params = oracle.default_params(oracle.MODEL_SINGLE_TRACK_LIMITED, T)
+    mine = run_batch(gpu_lib, mid, x0, None, T, 0.5, strategy, max_outer=outer, params=params)
+    builtin = run_batch(gpu_lib, oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, T, 0.5, strategy, max_outer=outer)
+    c = oracle.solve_batch(oid, x0, None, T, 0.5, strategy=strategy, max_outer=outer, params=params)
+    for key in ("cost", "X", "U"):
+        assert np.array_equal(mine[key], builtin[key]) and np.array_equal(mine[key], c[key]), key
+    assert mine["iters"].tolist() == builtin["iters"].tolist() == c["iters"].tolist()
+
+
 def test_the_second_registration_loads_the_cached_plugin(gpu_lib, user_single_track):
     import time
     from multi_agent_solver_amd.batch import register_model

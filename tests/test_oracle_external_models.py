@@ -89,3 +89,38 @@ def test_an_external_model_with_analytic_hooks_is_the_built_in_lane_following_mo
     a = oracle.solve_batch(mid, x0, None, T, 0.1, strategy=strategy, max_outer=outer, params=params)
     for key in ("cost", "X", "U", "iters"):
         assert np.array_equal(a[key], b[key]), key
+
+
+# function constraints of a user workload (ocp.hpp:61-68): NEQ / NIN + equality() / inequality() of the struct; the constrained test workload
+# (model 6: single track, steering tied to the acceleration, speed limits) written as a user struct
+USER_LIMITED = r"""
+struct UserLimited : FdModel<UserLimited, 4, 2> {
+  static constexpr int NEQ = 1, NIN = 2;
+  static constexpr bool kDefaultBounds = true;
+  MAS_HD static void default_bounds(double* lb, double* ub) { lb[0] = lb[1] = -0.5; ub[0] = ub[1] = 0.5; }
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    const double psi = x[2], v = x[3], L = P.p[6];
+    d[0] = v * mas_dt_cos(psi); d[1] = v * mas_dt_sin(psi); d[2] = (v * mas_dt_tan(u[0])) / L; d[3] = u[1];
+  }
+  MAS_HD static double stage_cost(const double* s, const double* c, int, const ModelParams& P) {
+    const double dist = fabs(sqrt(s[0] * s[0] + s[1] * s[1]) - P.p[0]);
+    const double se = s[3] - P.p[1];
+    return P.p[2] * dist * dist + P.p[3] * se * se + P.p[4] * c[0] * c[0] + P.p[5] * c[1] * c[1];
+  }
+  MAS_HD static double terminal_cost(const double*, const ModelParams&) { return 0.0; }
+  MAS_HD static void equality(const double*, const double* u, double* out, const ModelParams& P) { out[0] = u[0] - P.p[9] * u[1]; }
+  MAS_HD static void inequality(const double* x, const double*, double* out, const ModelParams& P) { out[0] = x[3] - P.p[8]; out[1] = -x[3]; }
+};
+"""
+
+
+@pytest.mark.parametrize("strategy,outer", [("single", 1), ("sequential", 2)])
+def test_an_external_model_with_function_constraints_is_the_built_in_constrained_model(oracle, strategy, outer):
+    mid = oracle.register_model(USER_LIMITED, "UserLimited")
+    N, T = 6, 20
+    x0 = oracle.single_track_x0(N)
+    params = oracle.default_params(oracle.MODEL_SINGLE_TRACK_LIMITED, T)
+    b = oracle.solve_batch(oracle.MODEL_SINGLE_TRACK_LIMITED, x0, None, T, 0.5, strategy=strategy, max_outer=outer)
+    a = oracle.solve_batch(mid, x0, None, T, 0.5, strategy=strategy, max_outer=outer, params=params)
+    for key in ("cost", "X", "U", "iters"):
+        assert np.array_equal(a[key], b[key]), key
