@@ -55,6 +55,10 @@ struct NoConstraints {
 // (P.p[0..15] are the problem's constants, mas_hip_problem_desc::params; sin / cos / tan as mas_dt_sin / mas_dt_cos / mas_dt_tan.)
 // It may override what the built-in models set: default_bounds + kDefaultBounds, kZeroTerminal, Ctl / prepare / dynamics_c (the part of
 // f(x, u) that depends on the zero-order-hold control alone, evaluated once per RK4 step), kRolloutLevels / state_level.
+// The reference's OPTIONAL callbacks are members as well: a derivative hook (types.hpp:30-50) is `static constexpr bool kAnalyticA = true`
+// (kAnalyticB, kAnalyticLx, kAnalyticLu, kAnalyticLxx, kAnalyticLuu, kAnalyticLux, kAnalyticTerm) with A(x, u, out, P), B, lx(x, u, t, out, P), lu,
+// lxx, luu, lux, term_grad(x, out, P) + term_hess (column-major); function constraints (ocp.hpp:61-68) are NEQ / NIN with
+// equality(x, u, out, P) and inequality(x, u, out, P).  Whatever is not declared stays finite-differenced / absent (ocp.hpp:117-171).
 struct NoCtl {};
 template <class Self, int NX_, int NU_>
 struct FdModel : NoConstraints {

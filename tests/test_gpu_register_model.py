@@ -77,6 +77,27 @@ struct WheeledArm : FdModel<WheeledArm, 5, 2> {                 // a unicycle ca
 };
 """
 
+SIX_BY_THREE = r"""
+struct SixByThree : FdModel<SixByThree, 6, 3> {                 // two coupled, damped double integrators with a steering-like third axis
+  MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) {
+    d[0] = x[3] + 0.1 * mas_dt_sin(x[2]);
+    d[1] = x[4];
+    d[2] = x[5] - 0.2 * x[2];
+    d[3] = u[0] - P.p[0] * x[3] * fabs(x[3]) + 0.3 * x[1];
+    d[4] = u[1] - 0.4 * x[4] + 0.2 * x[0] * mas_dt_cos(x[2]);
+    d[5] = u[2] - 0.5 * x[5];
+  }
+  MAS_HD static double stage_cost(const double* x, const double* u, int, const ModelParams& P) {
+    const double e0 = x[0] - P.p[1], e1 = x[1] - P.p[2];
+    return e0 * e0 + 0.8 * e1 * e1 + 0.3 * x[2] * x[2] + 0.1 * (x[3] * x[3] + x[4] * x[4] + x[5] * x[5]) + 0.05 * (u[0] * u[0] + u[1] * u[1]) + 0.02 * u[2] * u[2];
+  }
+  MAS_HD static double terminal_cost(const double* x, const ModelParams& P) {
+    const double e0 = x[0] - P.p[1], e1 = x[1] - P.p[2];
+    return 5.0 * (e0 * e0 + e1 * e1) + x[3] * x[3] + x[4] * x[4];
+  }
+};
+"""
+
 SINGLE_TRACK_PARAMS = [20.0, 5.0, 1.0, 1.0, 0.001, 0.001, 2.5] + [0.0] * 9
 
 
@@ -188,6 +209,27 @@ def test_a_user_model_with_function_constraints(gpu_lib, oracle, strategy, outer
     for key in ("cost", "X", "U"):
         assert np.array_equal(mine[key], builtin[key]) and np.array_equal(mine[key], c[key]), key
     assert mine["iters"].tolist() == builtin["iters"].tolist() == c["iters"].tolist()
+
+
+@pytest.mark.parametrize("strategy,outer", [("sequential", 2), ("centralized", 1), ("trustregion", 2)])
+def test_a_six_state_three_control_workload(gpu_lib, oracle, strategy, outer):
+    """Tiles of 126 doubles: the centralised backward pass has LDS for 8 wavefronts per workgroup, not the 16 its widest form takes -- forms
+    that do not fit are not instantiated (found by tools/fuzz_models.py: the registration failed with the compiler's 'local memory exceeds limit')."""
+    from multi_agent_solver_amd.batch import register_model
+    mid, oid = register_model(SIX_BY_THREE, "SixByThree", lib=gpu_lib), oracle.register_model(SIX_BY_THREE, "SixByThree")
+    N, T = 150, 30
+    rng = np.random.default_rng(31)
+    x0 = rng.uniform(-1.0, 1.0, (N, 6))
+    params = np.array([0.2, 1.0, -0.5] + [0.0] * 13)
+    e = run_batch(gpu_lib, mid, x0, None, T, 0.1, strategy, max_outer=outer, params=params, no_input_bounds=True)
+    c = oracle.solve_batch(oid, x0, None, T, 0.1, strategy=strategy, max_outer=outer, params=params)
+    for key in ("cost", "X", "U"):
+        assert np.array_equal(e[key], c[key]), key
+    assert e["iters"].tolist() == c["iters"].tolist()
+    if strategy == "centralized":       # every width of the shared ladder the LDS holds, and a request beyond it (clamped)
+        for wpb in (16, 8, 2, 1):
+            other = run_batch(gpu_lib, mid, x0, None, T, 0.1, strategy, max_outer=outer, params=params, no_input_bounds=True, options={"central_wpb": wpb})
+            assert all(np.array_equal(e[key], other[key]) for key in ("cost", "X", "U", "iters"))
 
 
 def test_the_second_registration_loads_the_cached_plugin(gpu_lib, user_single_track):
