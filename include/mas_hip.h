@@ -127,6 +127,10 @@ int mas_hip_model_dims(int model_id, int* nx, int* nu);
  *                       MAS_HD static void dynamics(const double* x, const double* u, double* d, const ModelParams& P) { ... }
  *                       MAS_HD static double stage_cost(const double* x, const double* u, int t, const ModelParams& P) { ... }
  *                       MAS_HD static double terminal_cost(const double* x, const ModelParams& P) { ... } };
+ *                   1 <= NX, NU <= 8.  The reference's OPTIONAL callbacks are members of the same struct: a derivative hook (types.hpp:30-50)
+ *                   is `static constexpr bool kAnalyticA = true` + `A(x, u, out, P)` (likewise B, lx(x, u, t, out, P), lu, lxx, luu, lux,
+ *                   term_grad(x, out, P) + term_hess; column-major), function constraints (ocp.hpp:61-68) are NEQ / NIN + equality(x, u, out, P)
+ *                   / inequality(...); input bounds kDefaultBounds + default_bounds(lb, ub).  What is not declared is finite-differenced / absent.
  *   struct_name     its name
  *   source_root     tree that holds multi_agent_solver_amd/csrc and include (NULL: the tree this library was built in)
  *   model_id        out: the id to put into mas_hip_problem_desc::model_id (>= 100)
