@@ -139,7 +139,7 @@ int mas_hip_model_dims(int model_id, int* nx, int* nu);
  * process.  Needs hipcc at run time; MAS_HIP_ERR_INVALID with the compiler's messages in mas_hip_last_error(NULL) when the source
  * does not compile.  Compiled plugins are kept (MAS_HIP_MODEL_CACHE, default /tmp/mas_hip_models_<uid>; the key is a hash of the struct, its
  * name and every header it is compiled against): registering the same workload again -- every start of an application -- loads the plugin
- * at once.  Process-wide, thread-safe, not undone. */
+ * at once.  Process-wide, thread-safe (registrations from several threads compile side by side), not undone. */
 int mas_hip_register_model(const char* struct_source, const char* struct_name, const char* source_root, int* model_id);
 int mas_hip_model_default_params(int model_id, int horizon_steps, double* params16);
 int mas_hip_create(const mas_hip_problem_desc* desc, mas_hip_solver** out);

@@ -113,7 +113,9 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
   for (const char* c = struct_name; *c; ++c)
     if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9' && c != struct_name) || *c == '_')) { g_create_error = "struct_name is not an identifier"; return MAS_HIP_ERR_INVALID; }
   if (source_root) for (const char* c = source_root; *c; ++c) if (*c == '\'' || *c == '\n') { g_create_error = "source_root must not contain quotes or line breaks"; return MAS_HIP_ERR_INVALID; }
-  std::lock_guard<std::mutex> lock(g_register_mutex);
+  // (the registry, dlopen and the cache directory are touched under the mutex; the compiler runs outside it, so several workloads
+  // registered from several threads compile side by side)
+  std::unique_lock<std::mutex> lock(g_register_mutex);
   // the headers: <root>/multi_agent_solver_amd/csrc and <root>/include; by default the tree this library was built in
   std::string root = source_root ? source_root : "";
   if (root.empty()) { const std::string lib = directory_of_this_library(); root = lib + "/../.."; }
@@ -152,7 +154,10 @@ int register_model_impl(const char* struct_source, const char* struct_name, cons
     }
     // the options libmas_hip.so itself is built with (__graft_entry__.py): nothing is contracted, IEEE division and square root
     const std::string cmd = "'" + cc + "' --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -shared -I'" + csrc + "' -I'" + inc + "' '" + src + "' -o '" + so + "' > '" + log + "' 2>&1";
-    if (std::system(cmd.c_str()) != 0 || !file_exists(so)) { g_create_error = "the model did not compile (" + log + "):\n" + tail_of_file(log, 2000); return MAS_HIP_ERR_INVALID; }
+    lock.unlock();
+    const int compiler_status = std::system(cmd.c_str());
+    lock.lock();
+    if (compiler_status != 0 || !file_exists(so)) { g_create_error = "the model did not compile (" + log + "):\n" + tail_of_file(log, 2000); return MAS_HIP_ERR_INVALID; }
     std::remove(src.c_str()); std::remove(log.c_str());
     if (std::rename(so.c_str(), cached.c_str()) == 0) { so = cached; (void)rmdir(d.c_str()); }      // (a rename inside one file system; otherwise the plugin is loaded from where it was built)
   }

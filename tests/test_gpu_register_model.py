@@ -104,6 +104,16 @@ SINGLE_TRACK_PARAMS = [20.0, 5.0, 1.0, 1.0, 0.001, 0.001, 2.5] + [0.0] * 9
 @pytest.fixture(scope="module")
 def gpu_lib(product_lib):
     assert product_lib.mas_hip_device_count() > 0
+    # the module's six workloads, registered from six threads: the library runs the compiler outside its registry lock, so they compile side by
+    # side (one compile time instead of six) and the tests below find their plugins in the cache
+    from concurrent.futures import ThreadPoolExecutor
+    from multi_agent_solver_amd.batch import register_model
+    from test_oracle_external_models import USER_LANE, USER_LIMITED
+    structs = [(USER_SINGLE_TRACK, "UserSingleTrack"), (DRAG_CART, "DragCart"), (WHEELED_ARM, "WheeledArm"), (SIX_BY_THREE, "SixByThree"),
+               (USER_LANE, "UserLane"), (USER_LIMITED, "UserLimited")]
+    with ThreadPoolExecutor(len(structs)) as pool:
+        ids = list(pool.map(lambda sn: register_model(sn[0], sn[1], lib=product_lib), structs))
+    assert len(set(ids)) == len(ids) and min(ids) >= 100
     return product_lib
 
 
