@@ -75,6 +75,20 @@ class HipError : public std::runtime_error {
   int code_;
 };
 
+// A workload of the caller's own.  The reference takes any std::function callbacks (types.hpp:21-50); device code cannot, so the caller
+// hands over the SOURCE of a struct with the same callbacks (mas::FdModel<Self, NX, NU>: dynamics, stage_cost, terminal_cost and whatever
+// optional hooks it declares, include/mas_hip.h) and gets the descriptor to put into OCP::model.  The first registration of a workload
+// compiles it against the kernel templates (about a minute of hipcc); later ones -- every further start of the program -- load the cached plugin.
+inline ModelDescriptor register_model(const std::string& struct_source, const std::string& struct_name,
+                                      std::optional<std::vector<double>> params = std::nullopt) {
+  int id = 0;
+  const int rc = mas_hip_register_model(struct_source.c_str(), struct_name.c_str(), nullptr, &id);
+  if (rc != MAS_HIP_OK) throw HipError(rc, std::string("mas_hip_register_model: ") + mas_hip_last_error(nullptr));
+  ModelDescriptor m;
+  m.model_id = id; m.params = std::move(params);
+  return m;
+}
+
 namespace detail {
 
 // one mas_hip_solver handle for a homogeneous batch of agents

@@ -188,3 +188,24 @@ def test_block_list_sharded_over_the_device_plan_in_one_process(exe_dir, strateg
     strip = lambda out: "\n".join([re.sub(r" time_ms=\S+", "", out.splitlines()[0])] + out.splitlines()[1:])      # noqa: E731
     assert strip(one.stdout) == strip(three.stdout)                     # result line and every agent's trajectory table
     assert _result_line(one.stdout).group(3) == "100"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", ["sequential", "trustregion", "centralized"])
+def test_a_user_defined_workload_from_cpp(exe_dir, oracle, strategy):
+    """host/examples/user_defined_model.cpp: what a caller of the reference who writes an OCP with callbacks of their own writes here -- the
+    callbacks as a struct, registered from C++ (mas_amd::register_model).  The oracle compiles the SAME text (cut out of the example's source)
+    for the CPU: equal total cost as printed; 5 agents: the centralised strategy is the literal stacked solve."""
+    src = open(os.path.join(ROOT, "multi_agent_solver_amd", "host", "examples", "user_defined_model.cpp")).read()
+    struct = re.search(r'R"MODEL\((.*?)\)MODEL"', src, re.S).group(1)
+    r = _run(exe_dir, "user_defined_model", "--agents", "5", "--strategy", strategy, "--quiet")
+    assert r.returncode == 0, r.stderr
+    mid = oracle.register_model(struct, "ParkingUnicycle")
+    x0 = np.array([[2.0 + 0.5 * i, -1.0 + 0.25 * i * i, 0.125 * i] for i in range(5)])
+    o = oracle.solve_batch(mid, x0, None, 30, 0.1, strategy="centralized_dense" if strategy == "centralized" else strategy,
+                           params=np.array([1.0, 0.05, 20.0] + [0.0] * 13))
+    m = _result_line(r.stdout)
+    assert m.group(2) == strategy and m.group(3) == "5" and m.group(4) == f"{o['total_cost']:.6f}"
+    # flag errors and --help never reach the compiler
+    r = _run(exe_dir, "user_defined_model", "--help")
+    assert r.returncode == 0 and "Usage: user_defined_model [--agents N]" in r.stdout
