@@ -200,6 +200,11 @@ struct CentralSelectBody {
   // agent's flag, which turns the kernels of an iteration enqueued behind it into no-ops (sweep, line search: no active agent;
   // backward pass: active[0]; this body: st->done; commit: alpha_sel = -1).
   int* active = nullptr;
+  // folded iterations (GPU build, run_centralized): this kernel is also the iteration's PUBLISHER -- the state and the word the host polls,
+  // stored by the thread that decided -- and it clears the words of the backward pass's rung agreement for the next iteration (the
+  // "gave up" flag after it has been published), so neither a commit kernel nor a memset stands between two iterations
+  Publish publish{};
+  unsigned long long* clear_words = nullptr; int n_clear_words = 0, n_clear_tail = 0;
 
   MAS_HD static void decide(const double* sums, double tolerance, CentralState* st) {
     const double cur = st->cur_total;
@@ -224,7 +229,11 @@ struct CentralSelectBody {
     __shared__ double sums[kNumAlphas];
     __shared__ int sel_sh;
     const int tid = threadIdx.x;
-    if (st->done != 0) { if (tid < n) alpha_sel[tid] = -1; return; }      // an iteration enqueued behind the last one (uniform: nobody has written st yet)
+    if (st->done != 0) {                                                 // an iteration enqueued behind the last one (uniform: nobody has written st yet)
+      if (tid < n) alpha_sel[tid] = -1;
+      if (tid == 0 && publish.host) publish();
+      return;
+    }
     const int wave = tid >> 6, n_waves = (static_cast<int>(blockDim.x) + 63) >> 6;
     for (int j = wave; j < kNumAlphas; j += n_waves) {                  // one wavefront per alpha trial (several trials per wavefront if the block is small)
       const double s = wave_serial_sum(trial_merit + static_cast<size_t>(j) * d.Np, n);
@@ -232,7 +241,12 @@ struct CentralSelectBody {
     }
     __syncthreads();
     __shared__ int done_sh;
-    if (tid == 0) { decide(sums, tolerance, st); sel_sh = st->j_sel; done_sh = st->done; }
+    if (tid == 0) {
+      decide(sums, tolerance, st); sel_sh = st->j_sel; done_sh = st->done;
+      if (publish.host) publish();
+      for (int q = 0; q < n_clear_tail; ++q) clear_words[n_clear_words + q] = 0ull;        // (the flag: published above)
+    }
+    for (int q = tid; q < n_clear_words; q += static_cast<int>(blockDim.x)) clear_words[q] = 0ull;
     __syncthreads();
     if (tid < n) { apply(tid, sel_sh); if (active && done_sh) active[tid] = 0; }
   }

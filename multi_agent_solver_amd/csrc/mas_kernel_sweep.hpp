@@ -14,11 +14,16 @@ namespace mas {
 // shrinks with the number of active agents instead of leaving the lanes of retired agents idle.  A wavefront whose
 // 64 slots hold one aligned block of 64 consecutive agents (every wavefront while all agents are active) keeps
 // the contiguous full-line store path; any other wavefront scatters whole tile chunks (128 B per agent and chunk).
-template <class M>
+// COMMIT (the centralised strategy's iterations, no live list): the sweep also COMMITS the trial the previous iteration's select accepted
+// (x = best_x; u = best_u, ilqr.hpp:231-232).  A lane whose agent has alpha_sel >= 0 takes x_t, u_t from that trial plane instead of X, U
+// and stores them to X, U (the lanes of the last time step also x_T) -- whether or not the agent is still active --, so the copy kernel
+// between select and the next sweep goes away: the values linearised are the values the copy would have put there.
+struct SweepCommit { const double* Xs = nullptr; const double* Us = nullptr; const int* alpha_sel = nullptr; double* Xw = nullptr; double* Uw = nullptr; };
+template <class M, bool COMMIT = false>
 __global__ void __launch_bounds__(256, 2) mas_sweep_kernel(Dims d, ModelParams P, const double* __restrict__ X, const double* __restrict__ U,
                                                         double* __restrict__ D, const int* __restrict__ active, int lo, int n,
                                                         unsigned long long* __restrict__ stamp,
-                                                        const int* __restrict__ live_list, const int* __restrict__ live_count) {
+                                                        const int* __restrict__ live_list, const int* __restrict__ live_count, SweepCommit cm) {
   using L = DerivLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, ND = L::ND;
   constexpr int CH = 16;              // tile elements staged per pass
@@ -50,12 +55,36 @@ __global__ void __launch_bounds__(256, 2) mas_sweep_kernel(Dims d, ModelParams P
     act = (a < n) && active[a] != 0;
   }
   const unsigned long long mask = __ballot(act);
-  if (mask == 0ull) return;                                // wave-uniform: nothing to linearise in this group
+  int jsel = -1;
+  if constexpr (COMMIT) { if (a >= 0 && a < n) jsel = cm.alpha_sel[a]; }
+  if constexpr (COMMIT) {
+    if (mask == 0ull && __ballot(jsel >= 0) == 0ull) return;
+  } else {
+    if (mask == 0ull) return;                              // wave-uniform: nothing to linearise in this group
+  }
   const int a_first = __builtin_amdgcn_readfirstlane(a);   // agent of the first active lane
   const bool one_block = (live_list == nullptr) ||
                          (mask == ~0ull && (a_first & 63) == 0 && __ballot(a == a_first + lane) == ~0ull);
 
   double Dl[ND];
+  if constexpr (COMMIT) {
+    double x[NX], u[NU];
+    const bool pend = jsel >= 0;
+    if (act || pend) {
+      const double* Xr = pend ? cm.Xs + static_cast<size_t>(jsel) * (d.T + 1) * NX * d.Np : X;
+      const double* Ur = pend ? cm.Us + static_cast<size_t>(jsel) * d.T * NU * d.Np : U;
+      MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = MAS_AT(Xr, t * NX + i, a);
+      MAS_UNROLL for (int i = 0; i < NU; ++i) u[i] = MAS_AT(Ur, t * NU + i, a);
+      if (pend) {
+        MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(cm.Xw, t * NX + i, a) = x[i];
+        MAS_UNROLL for (int i = 0; i < NU; ++i) MAS_AT(cm.Uw, t * NU + i, a) = u[i];
+        if (t == d.T - 1) { MAS_UNROLL for (int i = 0; i < NX; ++i) MAS_AT(cm.Xw, d.T * NX + i, a) = MAS_AT(Xr, d.T * NX + i, a); }
+      }
+    }
+    if (mask == 0ull) return;                              // wave-uniform: only copies in this group
+    if (act) linearise<M>(x, u, t, Dl, P);
+    else { MAS_UNROLL for (int i = 0; i < ND; ++i) Dl[i] = 0.0; }
+  } else {
   if (act) {
     double x[NX], u[NU];
     MAS_UNROLL for (int i = 0; i < NX; ++i) x[i] = MAS_AT(X, t * NX + i, a);
@@ -63,6 +92,7 @@ __global__ void __launch_bounds__(256, 2) mas_sweep_kernel(Dims d, ModelParams P
     linearise<M>(x, u, t, Dl, P);
   } else {
     MAS_UNROLL for (int i = 0; i < ND; ++i) Dl[i] = 0.0;
+  }
   }
 
   double* st = stage[w];

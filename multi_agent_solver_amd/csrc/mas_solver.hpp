@@ -100,6 +100,7 @@ class SolverBase {
     long long trust_fused_max = 4096;       // chained trust-region epilogue as ONE kernel (re-roll by dependency levels, mas_kernel_levels.hpp) up to this many live agents (0: never)
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
+    bool central_fold = true;               // centralised iterations in four launches: the sweep commits, the select publishes and clears (false: commit kernel + memset)
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
     bool fused_trust = true;                // chained trust-region epilogue inside the fused kernel (four-state FD models); false: the five-kernel round
     bool dense_ladder_blocked = true;       // chip-wide literal solve: the ladder's sixteen LLTs blocked by panels across the chip; false: one workgroup per rung, column by column
@@ -116,6 +117,7 @@ class SolverBase {
       else if (key == "trust_reroll_levels") trust_reroll_levels = v != 0;
       else if (key == "central_pipeline") central_pipeline = v != 0;
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
+      else if (key == "central_fold") central_fold = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
       else if (key == "dense_chip") dense_chip = v != 0;
       else if (key == "fused_trust") fused_trust = v != 0;
@@ -129,7 +131,7 @@ class SolverBase {
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
       static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
-                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust", "dense_ladder_blocked"};
+                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust", "dense_ladder_blocked", "central_fold"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
         for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
@@ -457,17 +459,20 @@ class SolverImpl final : public SolverBase {
       Marks& mk = marks[enq & 1];
       mk.p0 = be.mark(); mk.s0 = stamp_launches.size();
       const double nact = static_cast<double>(d.N);
-      launch_sweep(sweep_bytes() * nact);
+      // folded (GPU build): the sweep commits what the iteration before accepted, the select publishes -- no commit kernel in the loop
+      const bool folded = form_central_folded();
+      if (folded) form_sweep_commit(sweep_bytes() * nact); else launch_sweep(sweep_bytes() * nact);
       launch_central_backward(backward_bytes() * nact);
       launch_forward(make_forward(), forward_bytes() * nact * kNumAlphas, nullptr, nullptr, d.N);     // every agent active: slot == agent, CommitBody serves both forms
       // one wavefront per alpha trial for the ten serial sums (at least ten wavefronts, and a thread per agent for the bookkeeping)
-      be.launch_group("central_select", CentralSelectBody{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr}, d.N,
-                      0.0, 0, std::max(64 * kNumAlphas, static_cast<int>((d.N + 63) / 64 * 64)));
       static_assert(sizeof(CentralState) % sizeof(long long) == 0, "published word by word");
       Publish pub{reinterpret_cast<const long long*>(central), reinterpret_cast<long long*>(host_central + (enq & 1)), static_cast<int>(sizeof(CentralState) / sizeof(long long)),
                   ladder_error_flag()};
       pub.poll_word = host_counters + 24 + (enq & 1); pub.poll_tag = enq + 1; pub.poll_done = &central->done;
-      be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
+      CentralSelectBody sel{d, tolerance, trial_merit, cost, merit, alpha_sel, iters_total, central, run_ahead ? active : nullptr};
+      if (folded) { sel.publish = pub; form_central_select_extras(sel); }
+      be.launch_group("central_select", sel, d.N, 0.0, 0, std::max(64 * kNumAlphas, static_cast<int>((d.N + 63) / 64 * 64)));
+      if (!folded) be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, pub}, d.N, d.T + 1);
       mk.p1 = be.mark(); mk.s1 = stamp_launches.size();
       ++enq;
     };
@@ -499,7 +504,10 @@ class SolverImpl final : public SolverBase {
       }
       if (enq == r + 1 && enq < max_iterations) { if (timed_out(t0)) { exit_reason = kExitTime; break; } enqueue(); }
     }
-    be.sync();                                           // drains an iteration that ran ahead; the state below was published by the last commit
+    // folded iterations: the trial the LAST select accepted has no sweep behind it to commit it (an iteration that ran ahead has done so and
+    // reset alpha_sel: then this copies nothing)
+    if (enq > 0 && form_central_folded()) be.template launch_2d<4>("commit", CommitBody<M>{d, Xs, Us, alpha_sel, X, U, Publish{}}, d.N, d.T + 1);
+    be.sync();                                           // drains an iteration that ran ahead; the state below was published by the last commit / select
     if (ladder_gave_up) throw std::runtime_error("centralised backward pass: a wavefront gave up waiting for the rung agreement");   // (the flag is cleared with the words before every launch)
     // the state after the last executed iteration was published with it (an iteration enqueued behind the last one leaves it as it is);
     // only a solve without any iteration has to fetch what central_init wrote

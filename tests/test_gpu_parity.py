@@ -635,7 +635,18 @@ def test_centralized_speculative_pass_agrees(gpu_lib, oracle, model, N, T):
     new = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1)
     plain = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, options={"central_pipeline": 0})
     tile = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, options={"central_pipeline": 0, "backward_tile": 1})
-    for other in (plain, tile):
+    # round 4: an iteration is four launches -- the sweep commits what the iteration before accepted, the select publishes and clears the
+    # agreement's words; "central_fold": 0 gives commit kernel + memset back.  Also with an iteration limit that ends the solve on an
+    # ACCEPTED step (the last trial is committed by the copy behind the loop) and with a time limit (no iteration enqueued ahead).
+    unfolded = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, options={"central_fold": 0})
+    for kw in ({"max_iterations": 2}, {"max_ms": 1e7}):
+        a = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, **kw)
+        b = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, options={"central_fold": 0}, **kw)
+        assert all(np.array_equal(a[key], b[key]) for key in ("cost", "X", "U", "iters", "status")) and a["total_cost"] == b["total_cost"]
+    two = oracle.solve_batch(mid, x0, None, T, dt, strategy="centralized", max_outer=1, max_iterations=2)
+    a = run_batch(gpu_lib, mid, x0, None, T, dt, "centralized", max_outer=1, max_iterations=2)
+    assert np.array_equal(a["X"], two["X"]) and np.array_equal(a["U"], two["U"]) and np.array_equal(a["cost"], two["cost"])
+    for other in (plain, tile, unfolded):
         for key in ("cost", "X", "U", "iters"):
             assert np.array_equal(new[key], other[key]), key
         assert new["stats"]["reg_events"] == other["stats"]["reg_events"] and new["total_cost"] == other["total_cost"]
