@@ -97,6 +97,7 @@ def default_params(model_id: int, T: int) -> np.ndarray:
 
 
 _EXT_KEEP = []      # loaded shims and their callbacks stay alive
+_EXT_IDS = {}       # (struct_source, struct_name) -> id: a workload registered again gets the id it has (the C table holds 64 entries)
 
 
 def register_model(struct_source: str, struct_name: str) -> int:
@@ -107,12 +108,14 @@ def register_model(struct_source: str, struct_name: str) -> int:
     model id (>= 100) for solve_batch.  Test infrastructure: what it checks is the PRODUCT's treatment of the same struct."""
     import hashlib
     import tempfile
+    if (struct_source, struct_name) in _EXT_IDS:
+        return _EXT_IDS[(struct_source, struct_name)]
     root = os.path.dirname(_HERE)
     headers = b"".join(open(os.path.join(root, q), "rb").read() for q in ("multi_agent_solver_amd/csrc/mas_models.hpp", "multi_agent_solver_amd/csrc/mas_platform.hpp", "include/mas_dettrig.h"))
     tag = hashlib.sha256(b"shim v4" + (struct_source + struct_name).encode() + headers).hexdigest()[:16]
     d = os.path.join(tempfile.gettempdir(), f"mas_oracle_models_{os.getuid()}")
     os.makedirs(d, exist_ok=True)
-    so, src = os.path.join(d, f"{struct_name}_{tag}.so"), os.path.join(d, f"{struct_name}_{tag}.cpp")
+    so, src = os.path.join(d, f"{struct_name}_{tag}.so"), os.path.join(d, f"{struct_name}_{tag}.{os.getpid()}.cpp")
     if not os.path.exists(so):
         with open(src, "w") as f:
             f.write(f"""#define MAS_HOST_EMULATION 1
@@ -156,7 +159,9 @@ extern "C" int ext_hooks_mask() {{
 }}
 """)
         fma = ["-mfma"] if any(" fma " in l + " " for l in open("/proc/cpuinfo") if l.startswith("flags")) else []
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", *fma, "-fPIC", "-shared", src, "-o", so])
+        tmp_so = f"{so}.{os.getpid()}.tmp"       # (several test processes may build the same shim: the finished file appears at once)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", *fma, "-fPIC", "-shared", src, "-o", tmp_so])
+        os.replace(tmp_so, so)
     shim = C.CDLL(so)
     nx, nu = C.c_int(), C.c_int()
     lb, ub = (C.c_double * 8)(), (C.c_double * 8)()
@@ -187,6 +192,7 @@ extern "C" int ext_hooks_mask() {{
         if h(mid, C.cast(table, C.c_void_p)) != 0:
             raise RuntimeError("mas_oracle_external_set_hooks failed")
     _EXT_KEEP.append(shim)
+    _EXT_IDS[(struct_source, struct_name)] = mid
     return mid
 
 
