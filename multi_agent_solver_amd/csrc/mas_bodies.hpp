@@ -221,18 +221,23 @@ struct ForwardBody {
   const int* active;
   ALView al;
   Publish publish{};     // fused rounds (mas_fused_hip.hpp): the first lane publishes the counters of the select that ran in the kernel before
+  // staged line search (M::kStagedLineSearch): this launch rolls out the step sizes j_base, j_base + 1, ...; with stage_first set, only for agents
+  // whose FIRST trial (stage_first[a], written by the launch before) is no strict decrease of their merit stage_cur[a] -- SelectBody's comparison
+  int j_base = 0; const double* stage_first = nullptr; const double* stage_cur = nullptr;
   MAS_HD void operator()(int a, int j) const {
     constexpr int NX = M::NX, NU = M::NU;
     if (a == 0 && j == 0 && publish.host) publish();
+    j += j_base;
 #if defined(__HIP_DEVICE_COMPILE__)
     // A wavefront with at least one active agent rolls out ALL its 64 agents: a retired agent's lane costs nothing
     // extra (SIMD), its results go to its own unused trial slots and trial_merit entry (SelectBody ignores inactive
     // agents) -- but every store of the wavefront then covers whole 128-byte lines.  With the retired lanes masked
     // off the same stores are partial-line writes whose acknowledgements take so long that the in-order memory
     // counter throttles the wavefront: measured 373 us instead of 154 us per launch once few agents are active.
-    if (__ballot(active[a] != 0) == 0ull) return;
+    if (__ballot(active[a] != 0 && !(stage_first != nullptr && stage_first[a] < stage_cur[a])) == 0ull) return;
 #else
     if (!active[a]) return;
+    if (stage_first != nullptr && stage_first[a] < stage_cur[a]) return;
 #endif
     double alpha = 1.0;
     for (int q = 0; q < j; ++q) alpha *= 0.5;

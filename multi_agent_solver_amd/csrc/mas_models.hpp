@@ -41,6 +41,10 @@ struct NoConstraints {
   // kernel may skip the sums (the fused recursion does: mas_fused_hip.hpp; the other forms and the oracle form them, the results are held
   // against each other bit for bit)
   static constexpr bool kIdentityJacobians = false;
+  // true: the per-agent line search rolls out the FIRST step size alone and the nine further ones only for agents whose first trial did not
+  // decrease the merit (two launches; the select's decision is unchanged: it takes the first strict decrease in order).  For models whose full
+  // step nearly always succeeds and whose rollout is bound by the bytes of its trial planes (the identity LQR: 131 MB per launch for ten trials)
+  static constexpr bool kStagedLineSearch = false;
   MAS_HD static void equality(const double*, const double*, double*, const ModelParams&) {}
   MAS_HD static void inequality(const double*, const double*, double*, const ModelParams&) {}
 };
@@ -120,6 +124,7 @@ struct SingleTrack : NoConstraints {
 struct LqrIdentity : NoConstraints {
   static constexpr int NX = 4, NU = 4;
   static constexpr bool kIdentityJacobians = true;      // examples/multi_agent_lqr.cpp:35-41: A = B = I
+  static constexpr bool kStagedLineSearch = true;
   using Ctl = NoCtl;
   MAS_HD static Ctl prepare(const double*, const ModelParams&) { return Ctl{}; }
   MAS_HD static void dynamics_c(const double* x, const double* u, const Ctl&, double* d, const ModelParams& P) { dynamics(x, u, d, P); }

@@ -100,6 +100,7 @@ class SolverBase {
     long long trust_fused_max = 4096;       // chained trust-region epilogue as ONE kernel (re-roll by dependency levels, mas_kernel_levels.hpp) up to this many live agents (0: never)
     bool central_pipeline = true;           // centralised backward pass with the speculative step
     bool central_one_xcd = true;            // its working workgroups on one XCD
+    bool forward_staged = true;             // models with kStagedLineSearch (the identity LQR): first step size alone, the others only where it failed (false: all ten at once)
     bool central_fold = true;               // centralised iterations in four launches: the sweep commits, the select publishes and clears (false: commit kernel + memset)
     bool force_single_workgroup_central = false;   // the single-workgroup fallback of the shared ladder
     bool fused_trust = true;                // chained trust-region epilogue inside the fused kernel (four-state FD models); false: the five-kernel round
@@ -118,6 +119,7 @@ class SolverBase {
       else if (key == "central_pipeline") central_pipeline = v != 0;
       else if (key == "central_one_xcd") central_one_xcd = v != 0;
       else if (key == "central_fold") central_fold = v != 0;
+      else if (key == "forward_staged") forward_staged = v != 0;
       else if (key == "force_single_workgroup_central") force_single_workgroup_central = v != 0;
       else if (key == "dense_chip") dense_chip = v != 0;
       else if (key == "fused_trust") fused_trust = v != 0;
@@ -131,7 +133,7 @@ class SolverBase {
     void from_env() {
 #if defined(MAS_HIP_ENV_SWITCHES)
       static const char* keys[] = {"fused", "forward_quad_max", "backward_tile", "backward_list", "backward_wide_max", "backward_wave_max", "trust_fused_max", "trust_reroll_levels", "central_pipeline", "central_one_xcd",
-                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust", "dense_ladder_blocked", "central_fold"};
+                                   "force_single_workgroup_central", "central_combine", "central_wpb", "central_peek", "dense_chip", "fused_trust", "dense_ladder_blocked", "central_fold", "forward_staged"};
       for (const char* k : keys) {
         std::string name = "MAS_HIP_";
         for (const char* c = k; *c; ++c) name += static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
@@ -645,8 +647,19 @@ class SolverImpl final : public SolverBase {
   // per rollout once they no longer do -- the tail rounds of a solve, small batches, the centralised strategy's 256 agents --
   // where the launch time is one wavefront's chain and the quad form makes that chain ~40 % shorter.
   // live_count: device-side length of live_list (null: every agent, slot == agent); slots: host-side upper bound of it
-  bool launch_forward(const ForwardBody<M>& fwd, double bytes, const int* live_list, const int* live_count, long long slots) {
+  // staged_ok: the caller's select decides PER AGENT (SelectBody), so a model with kStagedLineSearch may roll out the first step size alone and
+  // the others only where it failed; the strategies that sum trial costs over agents (centralised, line-search Nash) need every trial
+  bool launch_forward(const ForwardBody<M>& fwd, double bytes, const int* live_list, const int* live_count, long long slots, bool staged_ok = false) {
     if (form_forward_by_slot(fwd, bytes, live_list, live_count, slots)) return true;
+    if constexpr (M::kStagedLineSearch && !kConstrained) {
+      if (staged_ok && switches.forward_staged) {
+        be.template launch_2d_range<kForwardTrialsPerBlock>("forward", fwd, 0, d.N, 1, bytes / kNumAlphas);
+        ForwardBody<M> rest = fwd;
+        rest.publish = Publish{}; rest.j_base = 1; rest.stage_first = trial_merit; rest.stage_cur = merit;
+        be.template launch_2d_range<kForwardTrialsPerBlock>("forward_further", rest, 0, d.N, kNumAlphas - 1, 0.0);
+        return false;
+      }
+    }
     be.template launch_2d_range<kForwardTrialsPerBlock>("forward", fwd, 0, d.N, kNumAlphas, bytes);
     return false;
   }
@@ -766,8 +779,8 @@ class SolverImpl final : public SolverBase {
       const int* list_now = live_lists[r & 1]; int* list_next = live_lists[(r + 1) & 1];
       launch_sweep(sweep_bytes(), 0, d.N, live, live ? static_cast<int>(live_upper) : d.N, list_now);
       launch_backward(backward_bytes(), 0, d.N, live ? list_now : nullptr, live, live_upper);
-      const bool by_slot = live ? launch_forward(fwd, forward_bytes() * kNumAlphas, list_now, live, live_upper)
-                                : launch_forward(fwd, forward_bytes() * kNumAlphas, nullptr, nullptr, std::numeric_limits<long long>::max());
+      const bool by_slot = live ? launch_forward(fwd, forward_bytes() * kNumAlphas, list_now, live, live_upper, true)
+                                : launch_forward(fwd, forward_bytes() * kNumAlphas, nullptr, nullptr, std::numeric_limits<long long>::max(), true);
       long long* ctr = counters + 2 * (r % kCounterRing);
       long long* ctr_clear = counters + 2 * ((r + 2) % kCounterRing);     // last read two rounds ago
       SelectBody sel{d, tolerance, max_iterations, trial_merit, cost, merit, active, alpha_sel, iters_solve,

@@ -530,6 +530,32 @@ def test_kernel_forms_agree(gpu_lib, oracle, model, T, dt, strategy, outer):
     _same(new, o, total_exact=(strategy != "centralized"))
 
 
+@pytest.mark.parametrize("N,T,strategy,outer,kw", [(330, 30, "sequential", 3, {}), (1700, 50, "sequential", 2, {}), (1, 7, "single", 1, {}), (70, 1, "trustregion", 2, {}),
+                                                   (65, 23, "linesearch", 2, {}), (200, 20, "centralized", 1, {}), (4096, 50, "sequential", 2, {}),
+                                                   (300, 25, "sequential", 3, {"input_bounds": ([-0.3] * 4, [0.3] * 4)}), (300, 25, "sequential", 2, {"max_iterations": 2})])
+def test_staged_line_search_of_the_identity_lqr(gpu_lib, oracle, N, T, strategy, outer, kw):
+    """kStagedLineSearch: the per-agent line search of the identity LQR rolls out the first step size alone and the nine further ones only for
+    agents whose first trial is no strict decrease (two launches instead of one with ten trials: a launch is bound by the bytes of its trial
+    planes).  Same decisions as all ten at once ("forward_staged": 0) -- in particular in the rounds in which NO trial decreases the merit (every
+    solve's last) and with input bounds that make the full step fail; the strategies that sum trial costs over agents keep all ten trials."""
+    rng = np.random.default_rng(43)
+    x0 = oracle.lqr_x0(N) + 0.1 * rng.standard_normal((N, 4))
+    run_kw = {k: v for k, v in kw.items() if k == "max_iterations"}
+    solver_kw = {}
+    if "input_bounds" in kw:
+        solver_kw["input_bounds"] = (np.array(kw["input_bounds"][0]), np.array(kw["input_bounds"][1]))
+    new = run_batch(gpu_lib, oracle.MODEL_LQR_IDENTITY, x0, None, T, 0.1, strategy, max_outer=outer, **run_kw, **solver_kw)
+    old = run_batch(gpu_lib, oracle.MODEL_LQR_IDENTITY, x0, None, T, 0.1, strategy, max_outer=outer, options={"forward_staged": 0}, **run_kw, **solver_kw)
+    for key in ("cost", "X", "U", "iters", "status"):
+        assert np.array_equal(new[key], old[key]), key
+    for key in ("reg_events", "agent_iterations", "converged_solves", "solves"):
+        assert new["stats"][key] == old["stats"][key], key
+    if strategy in ("sequential", "trustregion", "single") and "input_bounds" not in kw:
+        sample = np.arange(0, N, max(1, N // 40))
+        o = oracle.solve_batch(oracle.MODEL_LQR_IDENTITY, x0[sample], None, T, 0.1, strategy=strategy, max_outer=outer, **run_kw)
+        assert np.array_equal(new["cost"][sample], o["cost"]) and np.array_equal(new["X"][sample], o["X"]) and np.array_equal(new["U"][sample], o["U"])
+
+
 @pytest.mark.parametrize("model,N,T,dt,outer", [("MODEL_SINGLE_TRACK", 2100, 41, 0.5, 3), ("MODEL_SINGLE_TRACK", 1, 7, 0.5, 2), ("MODEL_SINGLE_TRACK", 17, 3, 0.5, 2),
                                                 ("MODEL_LQR_IDENTITY", 1700, 50, 0.1, 3), ("MODEL_SINGLE_TRACK_LANE", 1650, 30, 0.1, 2)])
 def test_fused_round_agrees_across_the_line_search_forms(gpu_lib, oracle, model, N, T, dt, outer):
