@@ -161,7 +161,11 @@ int mas_hip_check_params(const mas_hip_solver*);
  * one-lane against the four-lane line search); the defaults are the measured best.  The parity tests hold the forms against each
  * other through this entry point.  Keys: "fused" (0/1), "forward_quad_max" (live agents), "backward_tile" (0/1),
  * "backward_list" (0/1), "backward_wide_max" / "backward_wave_max" (live agents up to which the six-state backward pass uses 32 / 64 lanes per agent), "central_pipeline" (0/1), "central_one_xcd" (0/1), "force_single_workgroup_central" (0/1),
- * "central_combine" (0/1), "central_wpb" (1, 2, 4, 8, 16).  Unknown key or value: MAS_HIP_ERR_INVALID.  Results never depend on them. */
+ * "central_combine" (0/1), "central_peek" (0/1), "central_wpb" (1, 2, 4, 8, 16; clamped to what the CU's LDS holds for the model), "central_fold" (0/1: centralised
+ * iterations in four launches -- the sweep commits, the select publishes -- or with a commit kernel and a memset), "fused_trust" (0/1: the chained trust-region
+ * epilogue inside the fused kernel), "trust_fused_max" (live agents up to which the five-kernel round's epilogue is one kernel), "trust_reroll_levels" (0/1),
+ * "forward_staged" (0/1: models with kStagedLineSearch roll out the first step size alone and the others only where it failed), "dense_chip" (0/1: the literal
+ * centralised solve as chip-wide launches or in one workgroup), "dense_ladder_blocked" (0/1).  Unknown key or value: MAS_HIP_ERR_INVALID.  Results never depend on them. */
 int mas_hip_set_option(mas_hip_solver*, const char* key, int64_t value);
 
 /* ---- problem data: OCP::initial_state, OCP::best_controls (warm start, ilqr.hpp:72-75) ---- */
